@@ -1,0 +1,181 @@
+/*
+ * pt_amd.h -- C ABI of libpt_amd.so, the MI355X (gfx950) replacement for the
+ * radiance hot path of addrianyy/path-tracer.
+ *
+ * The reference has no FFI today.  The seam this ABI replaces is the one call
+ *     renderer.render(&context, &mut buffer, |ctx, rng, start, pixels|
+ *                         raytracer.render_fragment(start, pixels, &stats, rng))
+ * at src/main.rs:110-114, i.e. ParallelRenderer::render
+ * (src/parallel_renderer/mod.rs:155-203) driving Raytracer::render_fragment
+ * (src/raytracer.rs:98-123) and everything below it.  The Rust host keeps
+ * main.rs, the scene/material/texture builder API and image output; it packs
+ * its objects into the plain-old-data arrays below (INTEGRATION.md shows the
+ * `extern "C"` block and build.rs a maintainer would add).
+ *
+ * Conventions: every function returns PT_OK (0) or a negative pt_status; no
+ * exception or unwinding ever crosses this boundary; pt_last_error() returns a
+ * message for the most recent failure on that context.  The caller owns every
+ * pointer it passes; the library copies at upload time and keeps no host
+ * pointer after a call returns.  A context is used from one host thread at a
+ * time.  Pointers named d_* are DEVICE pointers on the context's GPU; all
+ * others are host pointers.
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_context pt_context;
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument (message says which)            */
+    PT_ERR_HIP = -2,       /* a HIP runtime call failed                    */
+    PT_ERR_NO_SCENE = -3,  /* render called before scene / camera upload   */
+    PT_ERR_NO_DEVICE = -4, /* no usable gfx950 device                      */
+    PT_ERR_LIMIT = -5      /* size beyond a documented maximum             */
+} pt_status;
+
+/* Sphere {center, radius, material}: src/traceable/sphere.rs:20-24.  `material`
+ * indexes the materials array (shared Arc<dyn Material>s de-duplicated by the
+ * host).  Primitive id = index in this array = Scene::add order
+ * (src/scene/mod.rs:46-48). */
+typedef struct {
+    float cx, cy, cz, radius;
+    int32_t material;
+} pt_sphere;
+
+/* src/material/{lambertian,metal,dielectric}.rs */
+enum { PT_LAMBERTIAN = 0, PT_METAL = 1, PT_DIELECTRIC = 2 };
+typedef struct {
+    int32_t kind;     /* PT_LAMBERTIAN / PT_METAL / PT_DIELECTRIC                      */
+    float albedo[3];  /* Lambertian::new_solid colour, Metal albedo; unused otherwise  */
+    float param;      /* Metal: fuziness (metal.rs:9); Dielectric: ref_idx             */
+    int32_t texture;  /* Lambertian::new(PictureTexture): texture index; else -1       */
+} pt_material;
+
+/* PictureTexture after image::open(..).into_rgb() (src/texture/picture.rs:9-13):
+ * decoded RGB8, row-major from the top row.  JPEG decoding stays on the host. */
+typedef struct {
+    int32_t width, height;
+    const uint8_t *rgb8;
+} pt_texture;
+
+/* The DERIVED fields of Camera (src/math/camera.rs:4-11).  Camera::new itself
+ * stays on the host (it uses tan and the rsqrt normalise, camera.rs:14-34);
+ * pt_camera_look_at below is a convenience that restates it. */
+typedef struct {
+    float lower_left_corner[3], origin[3], horizontal[3], vertical[3];
+    int32_t width, height;
+} pt_camera;
+
+/* One node of the flattened BvhNode tree (src/scene/bvh.rs:7-10) in DFS
+ * pre-order, left subtree before right.  skip = index of the first node after
+ * this node's subtree (node_count for the root).  prim = sphere index for a
+ * Leaf, -1 for a Split.  Bounds are the node's AABB (a Leaf's are never tested,
+ * bvh.rs:109). */
+typedef struct {
+    float bmin[3];
+    int32_t skip;
+    float bmax[3];
+    int32_t prim;
+} pt_bvh_node;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Replaces ParallelRenderer::new (src/parallel_renderer/mod.rs:73-153): instead of
+ * a CPU worker pool, binds HIP device `device` and creates the render stream. */
+int pt_create(int32_t device, pt_context **out);
+void pt_destroy(pt_context *ctx);
+const char *pt_last_error(const pt_context *ctx);   /* ctx may be NULL: create failures */
+
+/* Device facts for roofline reporting: name, CU count, clocks. */
+typedef struct {
+    char name[64];
+    char arch[32];
+    int32_t compute_units, wavefront_size, clock_khz, memory_clock_khz, l2_bytes;
+    int64_t hbm_bytes;
+} pt_device_info;
+int pt_query(const pt_context *ctx, pt_device_info *out);
+
+/* ---- scene -------------------------------------------------------------- */
+
+/* Replaces Raytracer::new (src/raytracer.rs:36-44): takes ownership of a copy of
+ * the scene and gets the BVH ready.  nodes == NULL / n_nodes == 0: the library
+ * builds the tree with the algorithm of src/scene/bvh.rs:13-91 (pt_bvh_build). */
+int pt_upload_scene(pt_context *ctx, const pt_sphere *spheres, int32_t n_spheres,
+                    const pt_material *materials, int32_t n_materials,
+                    const pt_texture *textures, int32_t n_textures,
+                    const pt_bvh_node *nodes, int32_t n_nodes);
+int pt_set_camera(pt_context *ctx, const pt_camera *camera);
+
+/* ---- render ------------------------------------------------------------- */
+
+/* Replaces renderer.render(..) at src/main.rs:110-114.  Blocking.  Renders sample
+ * indices s in [sample_begin, sample_end) of the samples x samples grid
+ * (s = sx * samples + sy, src/raytracer.rs:77-81); the full image is
+ * [0, samples*samples).  Per-(pixel,sample) RNG streams derive from `seed`.
+ * Outputs are host buffers, any may be NULL:
+ *   rgb8        W*H*3 bytes, row-major, top row first -- the `buffer` of main.rs:98,
+ *               resolved as sqrt(sum / samples^2) * 255 -> u8 (raytracer.rs:92-93,119-121).
+ *               Only meaningful when the range is the full grid.
+ *   radiance    W*H*3 fp32: the un-normalised radiance SUM over the range (AOV).
+ *   hit_id      W*H int32: primitive id hit by the primary ray of sample index 0,
+ *               -1 = miss (AOV; HitRecord has no id in the reference,
+ *               src/traceable/mod.rs:11-17 -- id = Scene::add order). */
+int pt_render(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end,
+              uint8_t *rgb8, float *radiance, int32_t *hit_id);
+
+/* Device-resident halves of pt_render, for callers that keep the radiance on the
+ * GPU (spp-sharded multi-GPU: render a sample range per GPU, reduce the fp32
+ * buffers with RCCL, resolve on the root).  Asynchronous on `stream` (a
+ * hipStream_t; NULL = the context's own stream).
+ *   pt_render_device : d_radiance[W*H*3] = (accumulate ? old : 0) + sum over the range
+ *   pt_resolve_device: d_rgb8[W*H*3] from d_radiance (raytracer.rs:92-93,119-121)
+ *   pt_primary_hits_device: d_hit_id[W*H] (and optional d_hit_t[W*H]) for sample index s */
+int pt_render_device(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
+                     int32_t sample_end, int32_t accumulate, float *d_radiance, void *stream);
+int pt_resolve_device(pt_context *ctx, int32_t samples, const float *d_radiance, uint8_t *d_rgb8, void *stream);
+int pt_primary_hits_device(pt_context *ctx, int32_t samples, int32_t sample_index, int32_t *d_hit_id,
+                           float *d_hit_t, void *stream);
+
+/* Milliseconds the path kernel of the most recent pt_render / pt_render_device
+ * took, measured with HIP events on the stream it was launched on.  Synchronises
+ * that stream.  Negative if no render has run. */
+float pt_last_path_kernel_ms(pt_context *ctx);
+
+/* How a pixel's samples are spread over GPU lanes.  0 (default) = automatic:
+ * one lane owns all samples of a pixel whenever the frame alone fills the GPU,
+ * which reproduces the reference's sequential fp32 sum order (raytracer.rs:88)
+ * bit for bit; small frames split each pixel's range into `lanes` contiguous
+ * chunks summed in order.  n > 0 forces n lanes per pixel. */
+int pt_set_lanes_per_pixel(pt_context *ctx, int32_t lanes);
+int pt_get_lanes_per_pixel(const pt_context *ctx, int32_t samples, int32_t sample_begin, int32_t sample_end);
+
+/* ---- host-side helpers (pure CPU, no GPU needed) ------------------------- */
+
+/* BvhNode::construct + pre-order flatten (src/scene/bvh.rs:13-91).  Returns the
+ * node count (2*n_spheres - 1) or a negative pt_status; capacity in nodes. */
+int32_t pt_bvh_build(const pt_sphere *spheres, int32_t n_spheres, pt_bvh_node *out, int32_t capacity);
+/* Camera::new (src/math/camera.rs:14-34), fov in degrees. */
+int pt_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_degrees,
+                      int32_t width, int32_t height, pt_camera *out);
+/* scene::generators::simple_scene (src/scene/generators.rs:8-23): 6 spheres, 6
+ * materials; material 0 expects texture 0 = decoded earthmap.  Returns 6. */
+int32_t pt_gen_simple_scene(pt_sphere *spheres, pt_material *materials);
+/* scene::generators::random_scene (src/scene/generators.rs:25-89) with a seeded
+ * Rng::with_seed(scene_seed) in place of Rng::new() and the grid bounds
+ * a in [a0,a1), b in [b0,b1) (reference: -22..22, -22..221).  One material per
+ * sphere.  Returns the sphere count, or -(count needed) if capacity is too small. */
+int32_t pt_gen_random_scene(uint64_t scene_seed, int32_t a0, int32_t a1, int32_t b0, int32_t b1,
+                            pt_sphere *spheres, pt_material *materials, int32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

@@ -1,0 +1,446 @@
+// pt_api.cpp -- the extern "C" boundary of libpt_amd.so (include/pt_amd.h).
+// Context / upload / launch plumbing only; the arithmetic lives in pt_device.hpp
+// and the kernels in pt_kernels.hip.  No exception leaves this file.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// lanes needed to give every SIMD of the chip a full complement of waves:
+// 256 CU x 4 SIMD x 8 waves x 64 lanes (MI355X_MICROARCH.md "Chip-level parameters")
+constexpr int64_t kFullChipLanes = 256ll * 4 * 8 * 64;
+
+}  // namespace
+
+struct pt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::string error;
+
+    // device scene
+    float4 *d_nodes = nullptr;
+    float4 *d_spheres = nullptr;
+    int32_t *d_sphere_material = nullptr;
+    float4 *d_mat_a = nullptr;
+    int2 *d_mat_b = nullptr;
+    ptd::Texture *d_textures = nullptr;
+    std::vector<uint8_t *> d_texels;
+    ptd::Scene scene{};
+    bool have_scene = false;
+
+    ptd::Camera camera{};
+    bool have_camera = false;
+
+    // frame-sized scratch for the host-buffer entry point pt_render
+    float *d_radiance = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    int32_t *d_hit_id = nullptr;
+    int64_t frame_pixels = 0;
+
+    int32_t lanes_override = 0;
+};
+
+namespace {
+
+int fail(pt_context *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define PT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail((ctx), PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+void free_scene(pt_context *c)
+{
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_spheres) (void)hipFree(c->d_spheres);
+    if (c->d_sphere_material) (void)hipFree(c->d_sphere_material);
+    if (c->d_mat_a) (void)hipFree(c->d_mat_a);
+    if (c->d_mat_b) (void)hipFree(c->d_mat_b);
+    if (c->d_textures) (void)hipFree(c->d_textures);
+    for (uint8_t *p : c->d_texels) (void)hipFree(p);
+    c->d_nodes = c->d_spheres = nullptr;
+    c->d_sphere_material = nullptr;
+    c->d_mat_a = nullptr;
+    c->d_mat_b = nullptr;
+    c->d_textures = nullptr;
+    c->d_texels.clear();
+    c->have_scene = false;
+}
+
+void free_frame(pt_context *c)
+{
+    if (c->d_radiance) (void)hipFree(c->d_radiance);
+    if (c->d_rgb8) (void)hipFree(c->d_rgb8);
+    if (c->d_hit_id) (void)hipFree(c->d_hit_id);
+    c->d_radiance = nullptr;
+    c->d_rgb8 = nullptr;
+    c->d_hit_id = nullptr;
+    c->frame_pixels = 0;
+}
+
+int ensure_frame(pt_context *c)
+{
+    const int64_t px = (int64_t)c->camera.width * c->camera.height;
+    if (px == c->frame_pixels) return PT_OK;
+    free_frame(c);
+    PT_HIP(c, hipMalloc((void **)&c->d_radiance, (size_t)px * 3 * sizeof(float)));
+    PT_HIP(c, hipMalloc((void **)&c->d_rgb8, (size_t)px * 3));
+    PT_HIP(c, hipMalloc((void **)&c->d_hit_id, (size_t)px * sizeof(int32_t)));
+    c->frame_pixels = px;
+    return PT_OK;
+}
+
+int check_ready(pt_context *c, int32_t samples)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "no scene uploaded (pt_upload_scene)");
+    if (!c->have_camera) return fail(c, PT_ERR_NO_SCENE, "no camera set (pt_set_camera)");
+    // samples == 1 divides 0/0 in the reference's grid (raytracer.rs:78): refuse it
+    if (samples < 2) return fail(c, PT_ERR_INVALID, "samples must be >= 2 (got %d)", samples);
+    if (samples > 1024) return fail(c, PT_ERR_LIMIT, "samples must be <= 1024 (got %d)", samples);
+    return PT_OK;
+}
+
+int pick_lanes(const pt_context *c, int32_t count)
+{
+    if (count < 1) count = 1;
+    int lanes = c->lanes_override;
+    if (lanes <= 0) {
+        const int64_t px = (int64_t)c->camera.width * c->camera.height;
+        lanes = 1;
+        while (lanes < 64 && px * lanes < kFullChipLanes) lanes *= 2;
+    }
+    while (lanes > 1 && lanes > count) lanes /= 2;   // never more lanes than samples
+    return lanes;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_create(int32_t device, pt_context **out)
+{
+    if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1)
+        return fail(nullptr, PT_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, PT_ERR_INVALID, "device %d out of range [0, %d)", device, count);
+    hipDeviceProp_t prop;
+    PT_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    pt_context *c = new (std::nothrow) pt_context();
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "out of host memory");
+    c->device = device;
+    PT_HIP(nullptr, hipSetDevice(device));
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, PT_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(pt_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_frame(c);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pt_last_error(const pt_context *c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int pt_query(const pt_context *c, pt_device_info *out)
+{
+    if (!c || !out) return PT_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return PT_ERR_HIP;
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", prop.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", prop.gcnArchName);
+    out->compute_units = prop.multiProcessorCount;
+    out->wavefront_size = prop.warpSize;
+    out->clock_khz = prop.clockRate;
+    out->memory_clock_khz = prop.memoryClockRate;
+    out->l2_bytes = prop.l2CacheSize;
+    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return PT_OK;
+}
+
+int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, const pt_material *materials,
+                    int32_t n_materials, const pt_texture *textures, int32_t n_textures, const pt_bvh_node *nodes,
+                    int32_t n_nodes)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!spheres || n_spheres < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one sphere (bvh.rs:19)");
+    if (!materials || n_materials < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one material");
+    if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, PT_ERR_INVALID, "bad texture array");
+    if (n_spheres > (1 << 28)) return fail(c, PT_ERR_LIMIT, "too many spheres (%d)", n_spheres);
+    for (int32_t i = 0; i < n_spheres; i++)
+        if (spheres[i].material < 0 || spheres[i].material >= n_materials)
+            return fail(c, PT_ERR_INVALID, "sphere %d: material index %d out of range [0, %d)", i, spheres[i].material, n_materials);
+    for (int32_t i = 0; i < n_materials; i++) {
+        const pt_material &m = materials[i];
+        if (m.kind < PT_LAMBERTIAN || m.kind > PT_DIELECTRIC) return fail(c, PT_ERR_INVALID, "material %d: unknown kind %d", i, m.kind);
+        if (m.kind == PT_LAMBERTIAN && m.texture >= n_textures)
+            return fail(c, PT_ERR_INVALID, "material %d: texture index %d out of range [0, %d)", i, m.texture, n_textures);
+    }
+    for (int32_t i = 0; i < n_textures; i++)
+        if (!textures[i].rgb8 || textures[i].width < 1 || textures[i].height < 1)
+            return fail(c, PT_ERR_INVALID, "texture %d: empty image", i);
+
+    // BVH: caller's flattened tree, or build it here (bvh.rs:13-91)
+    std::vector<pt_bvh_node> built;
+    const int32_t expect = 2 * n_spheres - 1;
+    if (!nodes || n_nodes == 0) {
+        try {
+            built.resize((size_t)expect);
+        } catch (...) {
+            return fail(c, PT_ERR_INVALID, "out of host memory");
+        }
+        const int32_t got = pt_bvh_build(spheres, n_spheres, built.data(), expect);
+        if (got != expect) return fail(c, PT_ERR_INVALID, "BVH build failed (%d)", got);
+        nodes = built.data();
+        n_nodes = got;
+    }
+    if (n_nodes != expect) return fail(c, PT_ERR_INVALID, "n_nodes = %d, a binary BVH over %d spheres has %d", n_nodes, n_spheres, expect);
+    // validate the walk the kernel will do: it follows skip links and prim ids unchecked
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const pt_bvh_node &nd = nodes[i];
+        if (nd.skip <= i || nd.skip > n_nodes) return fail(c, PT_ERR_INVALID, "node %d: skip %d not in (%d, %d]", i, nd.skip, i, n_nodes);
+        if (nd.prim >= n_spheres || nd.prim < -1) return fail(c, PT_ERR_INVALID, "node %d: prim %d out of range", i, nd.prim);
+        if (nd.prim >= 0 && nd.skip != i + 1) return fail(c, PT_ERR_INVALID, "node %d: a leaf's skip must be %d", i, i + 1);
+        if (nd.prim < 0 && i + 1 >= n_nodes) return fail(c, PT_ERR_INVALID, "node %d: split without children", i);
+    }
+
+    std::vector<float4> h_nodes, h_spheres, h_mat_a;
+    std::vector<int32_t> h_sm;
+    std::vector<int2> h_mat_b;
+    try {
+        h_nodes.resize(2 * (size_t)n_nodes);
+        h_spheres.resize((size_t)n_spheres);
+        h_sm.resize((size_t)n_spheres);
+        h_mat_a.resize((size_t)n_materials);
+        h_mat_b.resize((size_t)n_materials);
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
+    }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const pt_bvh_node &nd = nodes[i];
+        float4 a, b;
+        if (nd.prim < 0) {
+            a = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], 0.0f);
+            b = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.0f);
+            std::memcpy(&a.w, &nd.skip, 4);
+        } else {
+            const pt_sphere &s = spheres[nd.prim];
+            a = make_float4(s.cx, s.cy, s.cz, s.radius * s.radius);   // sphere.rs:51: radius * radius, one fp32 multiply
+            b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        std::memcpy(&b.w, &nd.prim, 4);
+        h_nodes[2 * (size_t)i] = a;
+        h_nodes[2 * (size_t)i + 1] = b;
+    }
+    for (int32_t i = 0; i < n_spheres; i++) {
+        h_spheres[i] = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, spheres[i].radius);
+        h_sm[i] = spheres[i].material;
+    }
+    for (int32_t i = 0; i < n_materials; i++) {
+        const pt_material &m = materials[i];
+        h_mat_a[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
+        h_mat_b[i] = make_int2(m.kind, m.kind == PT_LAMBERTIAN ? m.texture : -1);
+    }
+
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    PT_HIP(c, hipMalloc((void **)&c->d_nodes, h_nodes.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_spheres, h_spheres.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_sphere_material, h_sm.size() * sizeof(int32_t)));
+    PT_HIP(c, hipMalloc((void **)&c->d_mat_a, h_mat_a.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_mat_b, h_mat_b.size() * sizeof(int2)));
+    PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_spheres, h_spheres.data(), h_spheres.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_sphere_material, h_sm.data(), h_sm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_mat_a, h_mat_a.data(), h_mat_a.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_mat_b, h_mat_b.data(), h_mat_b.size() * sizeof(int2), hipMemcpyHostToDevice));
+    if (n_textures > 0) {
+        std::vector<ptd::Texture> h_tex((size_t)n_textures);
+        for (int32_t i = 0; i < n_textures; i++) {
+            const size_t bytes = (size_t)textures[i].width * (size_t)textures[i].height * 3;
+            uint8_t *d = nullptr;
+            PT_HIP(c, hipMalloc((void **)&d, bytes));
+            c->d_texels.push_back(d);
+            PT_HIP(c, hipMemcpy(d, textures[i].rgb8, bytes, hipMemcpyHostToDevice));
+            h_tex[i].rgb8 = d;
+            h_tex[i].width = textures[i].width;
+            h_tex[i].height = textures[i].height;
+        }
+        PT_HIP(c, hipMalloc((void **)&c->d_textures, h_tex.size() * sizeof(ptd::Texture)));
+        PT_HIP(c, hipMemcpy(c->d_textures, h_tex.data(), h_tex.size() * sizeof(ptd::Texture), hipMemcpyHostToDevice));
+    }
+    c->scene.nodes = c->d_nodes;
+    c->scene.spheres = c->d_spheres;
+    c->scene.sphere_material = c->d_sphere_material;
+    c->scene.mat_a = c->d_mat_a;
+    c->scene.mat_b = c->d_mat_b;
+    c->scene.textures = c->d_textures;
+    c->scene.n_nodes = n_nodes;
+    c->scene.n_spheres = n_spheres;
+    c->have_scene = true;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_context *c, const pt_camera *cam)
+{
+    if (!c || !cam) return PT_ERR_INVALID;
+    if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height > (1ll << 28))
+        return fail(c, PT_ERR_INVALID, "bad frame size %d x %d", cam->width, cam->height);
+    c->camera.llc = ptd::f3{cam->lower_left_corner[0], cam->lower_left_corner[1], cam->lower_left_corner[2]};
+    c->camera.origin = ptd::f3{cam->origin[0], cam->origin[1], cam->origin[2]};
+    c->camera.horizontal = ptd::f3{cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]};
+    c->camera.vertical = ptd::f3{cam->vertical[0], cam->vertical[1], cam->vertical[2]};
+    c->camera.width = cam->width;
+    c->camera.height = cam->height;
+    c->have_camera = true;
+    return PT_OK;
+}
+
+int pt_set_lanes_per_pixel(pt_context *c, int32_t lanes)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)) != 0))
+        return fail(c, PT_ERR_INVALID, "lanes per pixel must be 0 (auto) or a power of two in [1, 64], got %d", lanes);
+    c->lanes_override = lanes;
+    return PT_OK;
+}
+
+int pt_get_lanes_per_pixel(const pt_context *c, int32_t samples, int32_t sample_begin, int32_t sample_end)
+{
+    if (!c || !c->have_camera || samples < 2 || sample_end <= sample_begin) return PT_ERR_INVALID;
+    return pick_lanes(c, sample_end - sample_begin);
+}
+
+int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end,
+                     int32_t accumulate, float *d_radiance, void *stream)
+{
+    int rc = check_ready(c, samples);
+    if (rc != PT_OK) return rc;
+    if (!d_radiance) return fail(c, PT_ERR_INVALID, "d_radiance is NULL");
+    if (sample_begin < 0 || sample_end > samples * samples || sample_begin > sample_end)
+        return fail(c, PT_ERR_INVALID, "sample range [%d, %d) not inside [0, %d)", sample_begin, sample_end, samples * samples);
+    PT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    RenderParams rp;
+    rp.seed = seed;
+    rp.S = samples;
+    rp.s0 = sample_begin;
+    rp.s1 = sample_end;
+    rp.lanes = pick_lanes(c, sample_end - sample_begin);
+    rp.accumulate = accumulate ? 1 : 0;
+    PT_HIP(c, hipEventRecord(c->ev_start, st));
+    PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, d_radiance, st));
+    PT_HIP(c, hipEventRecord(c->ev_stop, st));
+    c->timed = true;
+    return PT_OK;
+}
+
+int pt_resolve_device(pt_context *c, int32_t samples, const float *d_radiance, uint8_t *d_rgb8, void *stream)
+{
+    int rc = check_ready(c, samples);
+    if (rc != PT_OK) return rc;
+    if (!d_radiance || !d_rgb8) return fail(c, PT_ERR_INVALID, "NULL device buffer");
+    PT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    PT_HIP(c, ptk::launch_resolve(d_radiance, c->camera.width * c->camera.height, samples, d_rgb8, st));
+    return PT_OK;
+}
+
+int pt_primary_hits_device(pt_context *c, int32_t samples, int32_t sample_index, int32_t *d_hit_id, float *d_hit_t,
+                           void *stream)
+{
+    int rc = check_ready(c, samples);
+    if (rc != PT_OK) return rc;
+    if (sample_index < 0 || sample_index >= samples * samples)
+        return fail(c, PT_ERR_INVALID, "sample index %d not in [0, %d)", sample_index, samples * samples);
+    if (!d_hit_id && !d_hit_t) return fail(c, PT_ERR_INVALID, "no output buffer");
+    PT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    PT_HIP(c, ptk::launch_primary_hits(c->scene, c->camera, samples, sample_index, d_hit_id, d_hit_t, st));
+    return PT_OK;
+}
+
+int pt_render(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end, uint8_t *rgb8,
+              float *radiance, int32_t *hit_id)
+{
+    int rc = check_ready(c, samples);
+    if (rc != PT_OK) return rc;
+    PT_HIP(c, hipSetDevice(c->device));
+    rc = ensure_frame(c);
+    if (rc != PT_OK) return rc;
+    const size_t px = (size_t)c->frame_pixels;
+    if (rgb8 || radiance) {
+        rc = pt_render_device(c, samples, seed, sample_begin, sample_end, 0, c->d_radiance, nullptr);
+        if (rc != PT_OK) return rc;
+    }
+    if (rgb8) {
+        rc = pt_resolve_device(c, samples, c->d_radiance, c->d_rgb8, nullptr);
+        if (rc != PT_OK) return rc;
+        PT_HIP(c, hipMemcpyAsync(rgb8, c->d_rgb8, px * 3, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (radiance) PT_HIP(c, hipMemcpyAsync(radiance, c->d_radiance, px * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hit_id) {
+        rc = pt_primary_hits_device(c, samples, 0, c->d_hit_id, nullptr, nullptr);
+        if (rc != PT_OK) return rc;
+        PT_HIP(c, hipMemcpyAsync(hit_id, c->d_hit_id, px * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+float pt_last_path_kernel_ms(pt_context *c)
+{
+    if (!c || !c->timed) return -1.0f;
+    if (hipSetDevice(c->device) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+}  // extern "C"

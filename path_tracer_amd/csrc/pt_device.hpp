@@ -1,0 +1,328 @@
+// pt_device.hpp -- device-side arithmetic of the radiance hot path, gfx950.
+//
+// Every function states the reference lines it reproduces (tree at
+// /root/reference).  The numeric contract is SURVEY.md section 9: each + - * /
+// sqrt is ONE correctly rounded fp32 operation in the reference's order; the
+// translation unit is compiled with -ffp-contract=off so hipcc never fuses
+// a*b+c (Rust never does), and HIP's default correctly rounded fp32 divide and
+// sqrt are kept.  Portable definitions P1-P3: RSQ(x) = 1/sqrt(x),
+// fp64-evaluated atan2f/asinf, per-(pixel,sample) xorshift64 streams.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+struct f3 { float x, y, z; };
+
+#define PTD __device__ __forceinline__
+
+PTD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTD f3 fill(float v) { return mk(v, v, v); }                                     // vec.rs:79
+PTD f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }     // vec.rs:145
+PTD f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }     // vec.rs:153
+PTD f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }     // vec.rs:177
+PTD f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }     // vec.rs:185
+PTD f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }        // vec.rs:161 (splat)
+PTD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }        // vec.rs:169 (splat)
+PTD f3 neg(f3 a) { return a * -1.0f; }                                           // vec.rs:137-142
+PTD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }        // vec.rs:32-36,99-101
+// P1: portable RSQ in place of _mm_rsqrt_ps (vec.rs:38-44)
+PTD float rsq(float x) { return 1.0f / __builtin_sqrtf(x); }
+PTD f3 normalized(f3 a) { return a * rsq(dot(a, a)); }                           // vec.rs:95-97
+
+// _mm_min_ps / _mm_max_ps lane semantics (vec.rs:50-51): second operand if either is NaN
+PTD float sse_min(float a, float b) { return a < b ? a : b; }
+PTD float sse_max(float a, float b) { return a > b ? a : b; }
+
+// Rust `as i32` / `as u8`: truncate, saturate, NaN -> 0 (picture.rs:21-22, raytracer.rs:121)
+PTD int32_t trunc_sat_i32(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+PTD uint8_t trunc_sat_u8(float f)
+{
+    if (f != f) return 0;
+    if (f >= 255.0f) return 255;
+    if (f <= 0.0f) return 0;
+    return (uint8_t)f;
+}
+
+// ---- RNG (rng.rs) -----------------------------------------------------------
+PTD uint64_t rng_raw(uint64_t &s)                                                // rng.rs:50-60
+{
+    uint64_t x = s;
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    s = x;
+    return x;
+}
+PTD float rng_f32(uint64_t &s)                                                   // rng.rs:76-80
+{
+    uint32_t v = (uint32_t)rng_raw(s);
+    return (float)(v >> 8) / 16777216.0f;
+}
+PTD float rng_range(uint64_t &s, float mn, float mx) { return rng_f32(s) * (mx - mn) + mn; } // rng.rs:83-85
+// P3: seed of the (pixel, sample) stream, then Rng::with_seed (rng.rs:27-35)
+PTD uint64_t path_rng(uint64_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint64_t k = ((uint64_t)pixel << 32) | (uint64_t)sample;
+    uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    if (z == 0) z = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int i = 0; i < 10; i++) (void)rng_raw(z);
+    return z;
+}
+
+// ---- math/mod.rs ------------------------------------------------------------
+PTD f3 random_in_unit_sphere(uint64_t &rng)                                      // math/mod.rs:13-19
+{
+    float x = rng_range(rng, -1.0f, 1.0f);
+    float y = rng_range(rng, -1.0f, 1.0f);
+    float z = rng_range(rng, -1.0f, 1.0f);
+    return normalized(mk(x, y, z));
+}
+PTD f3 reflect(f3 d, f3 n) { return d - ((n * dot(d, n)) * 2.0f); }              // math/mod.rs:21-23
+PTD bool refract(f3 d, f3 n, float k, f3 &out)                                   // math/mod.rs:25-34
+{
+    float dt = dot(d, n);
+    float D = 1.0f - (k * k) * (1.0f - dt * dt);
+    if (D > 0.0f) {
+        out = ((d - n * dt) * k) - (n * __builtin_sqrtf(D));
+        return true;
+    }
+    return false;
+}
+PTD float schlick(float cosine, float ref_idx)                                   // math/mod.rs:36-45 (v^5 as written)
+{
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    float v = r0 + (1.0f - r0) * (1.0f - cosine);
+    float v2 = v * v;
+    float v4 = v2 * v2;
+    return v4 * v;
+}
+
+// ---- P2: portable atan2f / asinf (sphere.rs:9-10), fp64 core -----------------
+PTD double atan_unit(double q)
+{
+    double base = 0.0, t = q;
+    if (q > 0.41421356237309504880) { t = (q - 1.0) / (q + 1.0); base = 0.78539816339744830962; }
+    double z = t * t;
+    double p = 1.0 / 45.0;
+#pragma unroll
+    for (int k = 21; k >= 0; k--) {
+        double c = 1.0 / (double)(2 * k + 1);
+        p = c - z * p;
+    }
+    return base + t * p;
+}
+PTD double atan2_core(double y, double x)
+{
+    if (y != y || x != x) return __builtin_nan("");
+    double ay = __builtin_fabs(y), ax = __builtin_fabs(x), a;
+    if (ax == 0.0 && ay == 0.0) a = 0.0;
+    else if (ay > ax) a = 1.57079632679489661923 - atan_unit(ax / ay);
+    else a = atan_unit(ay / ax);
+    if (__builtin_signbit(x)) a = 3.14159265358979323846 - a;
+    return __builtin_signbit(y) ? -a : a;
+}
+PTD float p_atan2f(float y, float x) { return (float)atan2_core((double)y, (double)x); }
+PTD float p_asinf(float y)
+{
+    double yd = (double)y;
+    if (!(__builtin_fabs(yd) <= 1.0)) return __builtin_nanf("");
+    double c = __builtin_sqrt((1.0 - yd) * (1.0 + yd));
+    return (float)atan2_core(yd, c);
+}
+
+// ---- device scene -------------------------------------------------------------
+struct Texture { const uint8_t *rgb8; int32_t width, height; };
+struct Scene {
+    const float4 *nodes;     // 2 x float4 per node, DFS pre-order (layout: pt_kernels.hip)
+    const float4 *spheres;   // (cx, cy, cz, radius), Scene::add order
+    const int32_t *sphere_material;
+    const float4 *mat_a;     // (albedo r, g, b, param)
+    const int2 *mat_b;       // (kind, texture index or -1)
+    const Texture *textures;
+    int32_t n_nodes, n_spheres;
+};
+struct Camera {               // camera.rs:4-11
+    f3 llc, origin, horizontal, vertical;
+    int32_t width, height;
+};
+
+struct Ray { f3 o, d; };
+
+PTD Ray camera_ray(const Camera &c, float u, float v)                            // camera.rs:37-44
+{
+    Ray r;
+    r.o = c.origin;
+    r.d = ((c.llc + c.horizontal * u) + c.vertical * v) - c.origin;
+    return r;
+}
+// sample s = sx*S + sy of the grid of raytracer.rs:77-86
+PTD Ray sample_ray(const Camera &c, int S, int px, int py, int s)
+{
+    int sx = s / S, sy = s - sx * S;
+    float x = (float)px + ((float)sx / (float)(S - 1));
+    float u = x / (float)c.width;
+    float y = (float)py + ((float)sy / (float)(S - 1));
+    float v = 1.0f - (y / (float)c.height);
+    return camera_ray(c, u, v);
+}
+
+PTD f3 sphere_uv_color(const Scene &sc, int tex, f3 n)                           // sphere.rs:6-18 + picture.rs:17-38
+{
+    float phi = p_atan2f(n.z, n.x);
+    float theta = p_asinf(n.y);
+    const float pi = 3.14159265358979323846f;
+    float u = 1.0f - (phi + pi) / (2.0f * pi);
+    float v = (theta + pi / 2.0f) / pi;
+    Texture t = sc.textures[tex];
+    int32_t i = trunc_sat_i32(u * (float)t.width);
+    int32_t j = trunc_sat_i32(((1.0f - v) * (float)t.height) - 0.001f);
+    i = i < t.width - 1 ? i : t.width - 1;   i = i > 0 ? i : 0;                  // picture.rs:24-26
+    j = j < t.height - 1 ? j : t.height - 1; j = j > 0 ? j : 0;
+    const uint8_t *px = t.rgb8 + 3 * ((size_t)j * (size_t)t.width + (size_t)i);
+    return mk((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+// ---- Scene::trace (scene/mod.rs:24-34) over the flattened BvhNode tree ---------
+//
+// Node i occupies nodes[2i], nodes[2i+1]:
+//   Split: (bmin.x, bmin.y, bmin.z, bits(skip)) (bmax.x, bmax.y, bmax.z, bits(-1))
+//   Leaf : (c.x,    c.y,    c.z,    r*r)        (unused, unused, unused, bits(prim))
+// The walk is the iterative form of BvhNode::trace (bvh.rs:106-127): DFS pre-order,
+// left before right, max_t = closest hit so far; a Split is entered only if its
+// own box passes AABB::intersect (aabb.rs:25-36); a Leaf is traced without a box
+// test (bvh.rs:109); strict '<' keeps the first hit in DFS order on ties
+// (sphere.rs:57,63).
+//
+// REGULAR = every component of origin and of 1/direction is finite.  Then no
+// operand of the slab test can be NaN and IEEE min/max (one v_min/v_max each)
+// give the same tmin/tmax as the reference's _mm_min_ps/_mm_max_ps; the general
+// variant reproduces the SSE "second operand on NaN" rule explicitly.
+struct Hit { float t; int32_t prim; };
+
+template <bool REGULAR>
+PTD Hit traverse(const Scene &sc, const Ray &ray, f3 inv)
+{
+    const float T_MIN = 0.001f;
+    Hit h; h.t = 3.402823466e+38f; h.prim = -1;
+    const float a = dot(ray.d, ray.d);                                           // sphere.rs:49
+    int idx = 0;
+    const int n = sc.n_nodes;
+    while (idx < n) {
+        const float4 n0 = sc.nodes[2 * idx], n1 = sc.nodes[2 * idx + 1];
+        const int prim = __float_as_int(n1.w);
+        if (prim < 0) {                                                          // Split: aabb.rs:25-36
+            f3 v0 = (mk(n0.x, n0.y, n0.z) - ray.o) * inv;
+            f3 v1 = (mk(n1.x, n1.y, n1.z) - ray.o) * inv;
+            float mnx, mny, mnz, mxx, mxy, mxz;
+            if (REGULAR) {
+                mnx = __builtin_fminf(v0.x, v1.x); mny = __builtin_fminf(v0.y, v1.y); mnz = __builtin_fminf(v0.z, v1.z);
+                mxx = __builtin_fmaxf(v0.x, v1.x); mxy = __builtin_fmaxf(v0.y, v1.y); mxz = __builtin_fmaxf(v0.z, v1.z);
+            } else {
+                mnx = sse_min(v0.x, v1.x); mny = sse_min(v0.y, v1.y); mnz = sse_min(v0.z, v1.z);
+                mxx = sse_max(v0.x, v1.x); mxy = sse_max(v0.y, v1.y); mxz = sse_max(v0.z, v1.z);
+            }
+            float tmin = __builtin_fmaxf(T_MIN, __builtin_fmaxf(mnx, __builtin_fmaxf(mny, mnz)));
+            float tmax = __builtin_fminf(h.t, __builtin_fminf(mxx, __builtin_fminf(mxy, mxz)));
+            idx = (tmin < tmax) ? idx + 1 : __float_as_int(n0.w);
+        } else {                                                                 // Leaf: sphere.rs:46-69
+            f3 oc = ray.o - mk(n0.x, n0.y, n0.z);
+            float b = dot(oc, ray.d);
+            float c = dot(oc, oc) - n0.w;
+            float d = b * b - a * c;
+            if (d > 0.0f) {
+                float sq = __builtin_sqrtf(d);
+                float sol = (-b - sq) / a;
+                if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = prim; }
+                else {
+                    sol = (-b + sq) / a;
+                    if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = prim; }
+                }
+            }
+            idx = idx + 1;
+        }
+    }
+    return h;
+}
+
+PTD bool finite3(f3 v)
+{
+    return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z);
+}
+
+PTD Hit scene_trace(const Scene &sc, const Ray &ray)
+{
+    f3 inv = fill(1.0f) / ray.d;                                                 // scene/mod.rs:31
+    if (finite3(inv) && finite3(ray.o)) return traverse<true>(sc, ray, inv);
+    return traverse<false>(sc, ray, inv);
+}
+
+// ---- Material::scatter (material/*.rs) -----------------------------------------
+// returns false when the path is absorbed (metal.rs:29-31)
+PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
+{
+    const float4 sp = sc.spheres[h.prim];
+    const int m = sc.sphere_material[h.prim];
+    const float4 ma = sc.mat_a[m];
+    const int2 mb = sc.mat_b[m];
+    // Sphere::record (sphere.rs:37-42)
+    const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
+    const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));
+    if (mb.x == 0) {                                                             // lambertian.rs:32-45
+        f3 target = (p + n) + random_in_unit_sphere(rng);
+        att = (mb.y >= 0) ? sphere_uv_color(sc, mb.y, n) : mk(ma.x, ma.y, ma.z);
+        out.o = p; out.d = normalized(target - p);                               // ray.rs:19-24
+        return true;
+    }
+    if (mb.x == 1) {                                                             // metal.rs:22-32
+        f3 reflected = reflect(ray.d, n);
+        if (dot(reflected, n) > 0.0f) {
+            f3 fuzz = random_in_unit_sphere(rng) * ma.w;
+            att = mk(ma.x, ma.y, ma.z);
+            out.o = p; out.d = normalized(reflected + fuzz);
+            return true;
+        }
+        return false;
+    }
+    {                                                                            // dielectric.rs:20-50
+        const float ref_idx = ma.w;
+        const f3 dir = ray.d;
+        const float dt = dot(dir, n);
+        f3 outward; float ni_over_nt, cosine;
+        if (dt > 0.0f) { cosine = ref_idx * dt; outward = neg(n); ni_over_nt = ref_idx; }
+        else { cosine = -dt; outward = n; ni_over_nt = 1.0f / ref_idx; }
+        f3 reflected = reflect(dir, n);
+        f3 refracted;
+        att = fill(1.0f);
+        f3 nd = reflected;
+        if (refract(dir, outward, ni_over_nt, refracted)) {
+            float prob = schlick(cosine, ref_idx);
+            float r = rng_f32(rng);
+            nd = (r < prob) ? reflected : refracted;
+        }
+        out.o = p; out.d = normalized(nd);
+        return true;
+    }
+}
+
+PTD f3 sky(const Ray &ray, f3 att)                                               // raytracer.rs:67-70
+{
+    float t = 0.5f * (ray.d.y + 1.0f);
+    f3 color = (mk(1.0f, 1.0f, 1.0f) * (1.0f - t)) + (mk(0.5f, 0.7f, 1.0f) * t);
+    return color * att;
+}
+
+#undef PTD
+}  // namespace ptd

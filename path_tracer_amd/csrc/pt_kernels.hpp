@@ -1,0 +1,20 @@
+// pt_kernels.hpp -- launch interface between the C ABI (pt_api.cpp) and the kernels.
+#pragma once
+#include "pt_device.hpp"
+
+struct RenderParams {
+    uint64_t seed;
+    int32_t S;            // side of the sample grid (raytracer.rs:77-81); spp = S*S
+    int32_t s0, s1;       // sample-index range [s0, s1) rendered by this launch
+    int32_t lanes;        // lanes per pixel: power of two in [1, 64]
+    int32_t accumulate;   // continue the sum already in the radiance buffer
+};
+
+namespace ptk {
+int tiles_for(const ptd::Camera &cam, int lanes);
+hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, float *d_radiance,
+                       hipStream_t stream);
+hipError_t launch_primary_hits(const ptd::Scene &sc, const ptd::Camera &cam, int S, int sample, int32_t *d_hit_id,
+                               float *d_hit_t, hipStream_t stream);
+hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t *d_rgb8, hipStream_t stream);
+}  // namespace ptk

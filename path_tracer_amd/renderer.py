@@ -1,0 +1,152 @@
+"""``Raytracer`` and ``ParallelRenderer``: the reference's L3/L4 interface
+(src/raytracer.rs:29-44, src/parallel_renderer/mod.rs:61-66,73,155) with the CPU
+tile loop replaced by the gfx950 library.  Everything numeric happens in
+libpt_amd.so; this file is plumbing (ctypes + optional torch device buffers).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .scene import Camera, Scene
+
+
+class ParallelRenderer:
+    """Replaces ParallelRenderer::new (mod.rs:73-153): binds one MI355X instead of
+    spawning one worker per logical CPU.  One instance per GPU / per process."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        rc = _abi.lib().pt_create(int(device), C.byref(self._ctx))
+        if rc != _abi.PT_OK:
+            msg = _abi.lib().pt_last_error(None)
+            raise _abi.PtError(rc, msg.decode() if msg else "pt_create failed")
+        self.device = int(device)
+        self._raytracer = None
+
+    @classmethod
+    def new(cls, device=0):
+        return cls(device)
+
+    def close(self):
+        if self._ctx:
+            _abi.lib().pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        info = _abi.PtDeviceInfo()
+        _abi.check(self._ctx, _abi.lib().pt_query(self._ctx, C.byref(info)))
+        return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
+                "wavefront_size": info.wavefront_size, "clock_khz": info.clock_khz,
+                "memory_clock_khz": info.memory_clock_khz, "l2_bytes": info.l2_bytes, "hbm_bytes": info.hbm_bytes}
+
+    # -- scene binding --------------------------------------------------------------
+    def bind(self, raytracer):
+        """Upload the raytracer's scene + camera (the work Raytracer::new does once,
+        raytracer.rs:36-44, plus the H2D copy)."""
+        if self._raytracer is raytracer:
+            return
+        p = raytracer.packed
+        tex = p.texture_structs()
+        nodes = raytracer.nodes
+        _abi.check(self._ctx, _abi.lib().pt_upload_scene(
+            self._ctx, p.spheres, p.n_spheres, p.materials, p.n_materials, tex, len(p.textures),
+            nodes, len(nodes) if nodes is not None else 0))
+        _abi.check(self._ctx, _abi.lib().pt_set_camera(self._ctx, C.byref(raytracer.camera.pod)))
+        self._raytracer = raytracer
+
+    def set_lanes_per_pixel(self, lanes):
+        _abi.check(self._ctx, _abi.lib().pt_set_lanes_per_pixel(self._ctx, int(lanes)))
+
+    def lanes_per_pixel(self, samples, sample_begin, sample_end):
+        return _abi.lib().pt_get_lanes_per_pixel(self._ctx, samples, sample_begin, sample_end)
+
+    # -- the render call (main.rs:110-114) ------------------------------------------
+    def render(self, raytracer, buffer=None, seed=0, sample_range=None, radiance=False, hit_ids=False):
+        """Fill ``buffer`` ((H*W, 3) or (H, W, 3) uint8, row-major from the top row:
+        the ``buffer`` of main.rs:98) and return it.  ``radiance`` / ``hit_ids`` also
+        return the fp32 radiance-sum and primary-hit-id AOVs:
+        ``(buffer, radiance_or_None, hit_ids_or_None)``."""
+        self.bind(raytracer)
+        w, h, s = raytracer.width(), raytracer.height(), raytracer.samples
+        if buffer is None:
+            buffer = np.zeros((h, w, 3), dtype=np.uint8)
+        if buffer.dtype != np.uint8 or buffer.size != w * h * 3 or not buffer.flags["C_CONTIGUOUS"]:
+            raise ValueError("buffer must be a C-contiguous uint8 array of %d x %d pixels" % (w, h))
+        s0, s1 = sample_range if sample_range is not None else (0, s * s)
+        rad = np.zeros((h, w, 3), dtype=np.float32) if radiance else None
+        ids = np.zeros((h, w), dtype=np.int32) if hit_ids else None
+        _abi.check(self._ctx, _abi.lib().pt_render(
+            self._ctx, s, int(seed) & (2 ** 64 - 1), int(s0), int(s1), buffer.ctypes.data,
+            rad.ctypes.data if rad is not None else None, ids.ctypes.data if ids is not None else None))
+        if radiance or hit_ids:
+            return buffer, rad, ids
+        return buffer
+
+    # -- device-resident halves (spp-sharded multi-GPU) -----------------------------
+    def render_device(self, raytracer, d_radiance_ptr, seed=0, sample_range=None, accumulate=False, stream=None):
+        self.bind(raytracer)
+        s = raytracer.samples
+        s0, s1 = sample_range if sample_range is not None else (0, s * s)
+        _abi.check(self._ctx, _abi.lib().pt_render_device(
+            self._ctx, s, int(seed) & (2 ** 64 - 1), int(s0), int(s1), 1 if accumulate else 0,
+            C.c_void_p(d_radiance_ptr), C.c_void_p(stream) if stream else None))
+
+    def resolve_device(self, raytracer, d_radiance_ptr, d_rgb8_ptr, stream=None):
+        self.bind(raytracer)
+        _abi.check(self._ctx, _abi.lib().pt_resolve_device(
+            self._ctx, raytracer.samples, C.c_void_p(d_radiance_ptr), C.c_void_p(d_rgb8_ptr),
+            C.c_void_p(stream) if stream else None))
+
+    def primary_hits_device(self, raytracer, d_hit_id_ptr, d_hit_t_ptr=None, sample_index=0, stream=None):
+        self.bind(raytracer)
+        _abi.check(self._ctx, _abi.lib().pt_primary_hits_device(
+            self._ctx, raytracer.samples, int(sample_index), C.c_void_p(d_hit_id_ptr),
+            C.c_void_p(d_hit_t_ptr) if d_hit_t_ptr else None, C.c_void_p(stream) if stream else None))
+
+    def last_path_kernel_ms(self):
+        return float(_abi.lib().pt_last_path_kernel_ms(self._ctx))
+
+
+class Raytracer:
+    """raytracer.rs:29-44: camera + scene + samples; ``new`` builds the BVH
+    (Scene::construct_bvh, scene/mod.rs:50-60) -- here with pt_bvh_build on the host,
+    flattened for the GPU."""
+
+    def __init__(self, camera, scene, samples, build_bvh=True):
+        if not isinstance(camera, Camera) or not isinstance(scene, Scene):
+            raise TypeError("Raytracer.new(camera: Camera, scene: Scene, samples)")
+        if int(samples) < 2:
+            # samples == 1 divides 0/0 in the sample grid (raytracer.rs:78); the library refuses it too
+            raise ValueError("samples must be >= 2")
+        self.camera, self.samples = camera, int(samples)
+        self.packed = scene.pack()
+        self.nodes = self.packed.build_bvh() if build_bvh else None   # None: the library builds it at upload
+
+    @classmethod
+    def new(cls, camera, scene, samples):
+        return cls(camera, scene, samples)
+
+    def width(self):
+        return self.camera.width
+
+    def height(self):
+        return self.camera.height
+
+    def pixel_count(self):
+        return self.width() * self.height()
+
+
+def shard_range(samples, rank, world):
+    """Sample-index range of `rank` when the samples*samples grid is split over `world` GPUs
+    (contiguous, sizes differ by at most one)."""
+    total = samples * samples
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)

@@ -1,0 +1,193 @@
+"""ctypes binding of the CPU oracle (oracle/pt_oracle.c).  TEST INFRASTRUCTURE:
+imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(_ROOT, "oracle")
+
+
+class OraSphere(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("cz", C.c_float), ("radius", C.c_float),
+                ("material", C.c_int32)]
+
+
+class OraMaterial(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("albedo", C.c_float * 3), ("param", C.c_float), ("texture", C.c_int32)]
+
+
+class OraTexture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb8", C.c_void_p)]
+
+
+class OraCamera(C.Structure):
+    _fields_ = [("llc", C.c_float * 3), ("origin", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class OraNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("skip", C.c_int32), ("bmax", C.c_float * 3), ("prim", C.c_int32)]
+
+
+COUNTER_FIELDS = ["paths", "segments", "aabb_tests", "sphere_tests", "sphere_near_hits", "sphere_far_hits",
+                  "lambert", "lambert_textured", "metal_scatter", "metal_absorb", "dielectric_refract",
+                  "dielectric_tir", "rng_draws", "sky_evals"]
+
+
+class OraCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
+
+
+_F3 = C.POINTER(C.c_float)
+_libs = {}
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def load(fast=False):
+    """liboracle.so (parity build) or liboracle_fast.so (cost-faithful timing build)."""
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name not in _libs:
+        path = os.path.join(ORACLE_DIR, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.ora_rsqrt.restype, L.ora_rsqrt.argtypes = C.c_float, [C.c_float]
+        L.ora_rng_raw.restype, L.ora_rng_raw.argtypes = C.c_uint64, [C.POINTER(C.c_uint64)]
+        L.ora_rng_with_seed.restype, L.ora_rng_with_seed.argtypes = C.c_uint64, [C.c_uint64]
+        L.ora_rng_f32.restype, L.ora_rng_f32.argtypes = C.c_float, [C.POINTER(C.c_uint64)]
+        L.ora_path_seed.restype, L.ora_path_seed.argtypes = C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_atan2f.restype, L.ora_atan2f.argtypes = C.c_float, [C.c_float, C.c_float]
+        L.ora_asinf.restype, L.ora_asinf.argtypes = C.c_float, [C.c_float]
+        L.ora_schlick.restype, L.ora_schlick.argtypes = C.c_float, [C.c_float, C.c_float]
+        L.ora_reflect.restype, L.ora_reflect.argtypes = None, [_F3, _F3, _F3]
+        L.ora_refract.restype, L.ora_refract.argtypes = C.c_int, [_F3, _F3, C.c_float, _F3]
+        L.ora_aabb_intersect.restype = C.c_int
+        L.ora_aabb_intersect.argtypes = [_F3, _F3, _F3, _F3, C.c_float, C.c_float]
+        L.ora_sphere_trace.restype = C.c_int
+        L.ora_sphere_trace.argtypes = [_F3, C.c_float, _F3, _F3, C.c_float, C.c_float, _F3]
+        L.ora_sphere_uv.restype, L.ora_sphere_uv.argtypes = None, [_F3, _F3]
+        L.ora_texture_color.restype = None
+        L.ora_texture_color.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, _F3]
+        L.ora_camera_new.restype = None
+        L.ora_camera_new.argtypes = [_F3, _F3, _F3, C.c_float, C.c_int32, C.c_int32, C.POINTER(OraCamera)]
+        L.ora_resolve.restype, L.ora_resolve.argtypes = None, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        L.ora_scene_create.restype = C.c_void_p
+        L.ora_scene_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.ora_scene_destroy.restype, L.ora_scene_destroy.argtypes = None, [C.c_void_p]
+        L.ora_scene_node_count.restype, L.ora_scene_node_count.argtypes = C.c_int32, [C.c_void_p]
+        L.ora_scene_flatten.restype, L.ora_scene_flatten.argtypes = C.c_int32, [C.c_void_p, C.POINTER(OraNode), C.c_int32]
+        L.ora_render.restype = C.c_int
+        L.ora_render.argtypes = [C.c_void_p, C.POINTER(OraCamera), C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.POINTER(OraCounters)]
+        L.ora_trace_path.restype = None
+        L.ora_trace_path.argtypes = [C.c_void_p, C.POINTER(OraCamera), C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
+                                     C.c_int32, _F3]
+        L.ora_gen_simple_scene.restype = C.c_int32
+        L.ora_gen_simple_scene.argtypes = [C.POINTER(OraSphere), C.POINTER(OraMaterial)]
+        L.ora_gen_random_scene.restype = C.c_int32
+        L.ora_gen_random_scene.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.POINTER(OraSphere), C.POINTER(OraMaterial), C.c_int32]
+        _libs[name] = L
+    return _libs[name]
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+class OracleScene:
+    """An oracle scene built from the SAME plain arrays that cross the product's ABI
+    (a path_tracer_amd PackedScene: the struct layouts are identical by design)."""
+
+    def __init__(self, packed, fast=False):
+        self.L = load(fast)
+        self.packed = packed
+        ntex = len(packed.textures)
+        tex = (OraTexture * max(1, ntex))()
+        for i, t in enumerate(packed.textures):
+            tex[i].width, tex[i].height, tex[i].rgb8 = t.shape[1], t.shape[0], t.ctypes.data
+        self.handle = self.L.ora_scene_create(C.addressof(packed.spheres), packed.n_spheres,
+                                              C.addressof(packed.materials), packed.n_materials,
+                                              C.addressof(tex), ntex)
+        if not self.handle:
+            raise RuntimeError("ora_scene_create failed")
+
+    def close(self):
+        if self.handle:
+            self.L.ora_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def flatten(self):
+        n = self.L.ora_scene_node_count(self.handle)
+        nodes = (OraNode * n)()
+        assert self.L.ora_scene_flatten(self.handle, nodes, n) == n
+        return nodes
+
+    def render(self, camera_pod, samples, seed=0, sample_range=None, chunk=0, threads=None, radiance=True,
+               hit_ids=False, hit_t=False, aov_sample=0, counters=False):
+        """camera_pod: a path_tracer_amd PtCamera (same layout as ora_camera)."""
+        cam = OraCamera.from_buffer_copy(bytes(camera_pod))
+        w, h = cam.width, cam.height
+        s0, s1 = sample_range if sample_range is not None else (0, samples * samples)
+        threads = threads or min(16, os.cpu_count() or 1)
+        rad = np.zeros((h, w, 3), dtype=np.float32) if radiance else None
+        ids = np.zeros((h, w), dtype=np.int32) if hit_ids else None
+        ts = np.zeros((h, w), dtype=np.float32) if hit_t else None
+        cnt = OraCounters() if counters else None
+        rc = self.L.ora_render(self.handle, C.byref(cam), samples, int(seed) & (2 ** 64 - 1), s0, s1, chunk, threads,
+                               rad.ctypes.data if rad is not None else None,
+                               ids.ctypes.data if ids is not None else None,
+                               ts.ctypes.data if ts is not None else None, aov_sample,
+                               C.byref(cnt) if cnt is not None else None)
+        if rc != 0:
+            raise RuntimeError("ora_render rejected its arguments")
+        return {"radiance": rad, "hit_id": ids, "hit_t": ts, "counters": cnt.as_dict() if cnt is not None else None}
+
+    def resolve(self, radiance, samples):
+        rad = np.ascontiguousarray(radiance, dtype=np.float32)
+        out = np.zeros(rad.shape, dtype=np.uint8)
+        self.L.ora_resolve(rad.ctypes.data, rad.size // 3, samples, out.ctypes.data)
+        return out
+
+    def trace_path(self, camera_pod, samples, seed, px, py, s):
+        cam = OraCamera.from_buffer_copy(bytes(camera_pod))
+        out = (C.c_float * 3)()
+        self.L.ora_trace_path(self.handle, C.byref(cam), samples, int(seed), px, py, s, out)
+        return np.array(out[:], dtype=np.float32)
+
+
+# Algorithmic-flop model of SURVEY.md section 8(d): flops per event, counted with the
+# reference's own operation counts (1 per fp32 add/sub/mul/div/sqrt/rsqrt/min/max/compare).
+FLOPS = {
+    "camera_ray": 22, "trace_prologue": 3, "aabb_test": 25, "sphere_miss": 24, "sphere_near_hit": 30,
+    "sphere_far_hit": 35, "record": 18, "lambert": 36, "lambert_textured_extra": 20, "metal": 53, "metal_absorb": 20,
+    "dielectric": 73, "dielectric_tir": 42, "attenuation": 3, "sky": 15, "accumulate": 3,
+}
+
+
+def algorithmic_flops(c):
+    """Total algorithmic flops for a counters dict (ora_counters)."""
+    hits = c["sphere_near_hits"] + c["sphere_far_hits"]
+    misses = c["sphere_tests"] - hits
+    scatters = c["lambert"] + c["metal_scatter"] + c["dielectric_refract"] + c["dielectric_tir"]
+    f = FLOPS
+    return (c["paths"] * (f["camera_ray"] + f["accumulate"]) + c["segments"] * f["trace_prologue"]
+            + c["aabb_tests"] * f["aabb_test"] + misses * f["sphere_miss"]
+            + c["sphere_near_hits"] * f["sphere_near_hit"] + c["sphere_far_hits"] * f["sphere_far_hit"]
+            + hits * f["record"] + c["lambert"] * f["lambert"] + c["lambert_textured"] * f["lambert_textured_extra"]
+            + c["metal_scatter"] * f["metal"] + c["metal_absorb"] * f["metal_absorb"]
+            + c["dielectric_refract"] * f["dielectric"] + c["dielectric_tir"] * f["dielectric_tir"]
+            + scatters * f["attenuation"] + c["sky_evals"] * f["sky"])
