@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_amd.so")
+# PT_AMD_LIB: alternative build of the same library (kernel tuning experiments only)
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpt_amd.so")
 
 PT_OK = 0
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2

@@ -33,9 +33,8 @@ struct pt_context {
     // device scene
     float4 *d_nodes = nullptr;
     float4 *d_spheres = nullptr;
-    int32_t *d_sphere_material = nullptr;
-    float4 *d_mat_a = nullptr;
-    int2 *d_mat_b = nullptr;
+    float4 *d_shade_a = nullptr;
+    int2 *d_shade_b = nullptr;
     ptd::Texture *d_textures = nullptr;
     std::vector<uint8_t *> d_texels;
     ptd::Scene scene{};
@@ -77,15 +76,13 @@ void free_scene(pt_context *c)
 {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_spheres) (void)hipFree(c->d_spheres);
-    if (c->d_sphere_material) (void)hipFree(c->d_sphere_material);
-    if (c->d_mat_a) (void)hipFree(c->d_mat_a);
-    if (c->d_mat_b) (void)hipFree(c->d_mat_b);
+    if (c->d_shade_a) (void)hipFree(c->d_shade_a);
+    if (c->d_shade_b) (void)hipFree(c->d_shade_b);
     if (c->d_textures) (void)hipFree(c->d_textures);
     for (uint8_t *p : c->d_texels) (void)hipFree(p);
     c->d_nodes = c->d_spheres = nullptr;
-    c->d_sphere_material = nullptr;
-    c->d_mat_a = nullptr;
-    c->d_mat_b = nullptr;
+    c->d_shade_a = nullptr;
+    c->d_shade_b = nullptr;
     c->d_textures = nullptr;
     c->d_texels.clear();
     c->have_scene = false;
@@ -248,42 +245,44 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
         if (nd.prim < 0 && i + 1 >= n_nodes) return fail(c, PT_ERR_INVALID, "node %d: split without children", i);
     }
 
-    std::vector<float4> h_nodes, h_spheres, h_mat_a;
-    std::vector<int32_t> h_sm;
-    std::vector<int2> h_mat_b;
+    // device layout (pt_device.hpp): node codes carry the kind of the node they name
+    auto code_of = [&](int32_t i) -> int32_t {
+        return (i < n_nodes && nodes[i].prim >= 0) ? (int32_t)(i | 0x80000000u) : i;
+    };
+    std::vector<float4> h_nodes, h_spheres, h_shade_a;
+    std::vector<int2> h_shade_b;
     try {
         h_nodes.resize(2 * (size_t)n_nodes);
         h_spheres.resize((size_t)n_spheres);
-        h_sm.resize((size_t)n_spheres);
-        h_mat_a.resize((size_t)n_materials);
-        h_mat_b.resize((size_t)n_materials);
+        h_shade_a.resize((size_t)n_spheres);
+        h_shade_b.resize((size_t)n_spheres);
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
     for (int32_t i = 0; i < n_nodes; i++) {
         const pt_bvh_node &nd = nodes[i];
         float4 a, b;
+        const int32_t next = code_of(i + 1);
         if (nd.prim < 0) {
+            const int32_t skip = code_of(nd.skip);
             a = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], 0.0f);
             b = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.0f);
-            std::memcpy(&a.w, &nd.skip, 4);
+            std::memcpy(&a.w, &skip, 4);
         } else {
             const pt_sphere &s = spheres[nd.prim];
             a = make_float4(s.cx, s.cy, s.cz, s.radius * s.radius);   // sphere.rs:51: radius * radius, one fp32 multiply
             b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            std::memcpy(&b.z, &nd.prim, 4);
         }
-        std::memcpy(&b.w, &nd.prim, 4);
+        std::memcpy(&b.w, &next, 4);
         h_nodes[2 * (size_t)i] = a;
         h_nodes[2 * (size_t)i + 1] = b;
     }
     for (int32_t i = 0; i < n_spheres; i++) {
+        const pt_material &m = materials[spheres[i].material];
         h_spheres[i] = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, spheres[i].radius);
-        h_sm[i] = spheres[i].material;
-    }
-    for (int32_t i = 0; i < n_materials; i++) {
-        const pt_material &m = materials[i];
-        h_mat_a[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
-        h_mat_b[i] = make_int2(m.kind, m.kind == PT_LAMBERTIAN ? m.texture : -1);
+        h_shade_a[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
+        h_shade_b[i] = make_int2(m.kind, m.kind == PT_LAMBERTIAN ? m.texture : -1);
     }
 
     PT_HIP(c, hipSetDevice(c->device));
@@ -291,14 +290,12 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     free_scene(c);
     PT_HIP(c, hipMalloc((void **)&c->d_nodes, h_nodes.size() * sizeof(float4)));
     PT_HIP(c, hipMalloc((void **)&c->d_spheres, h_spheres.size() * sizeof(float4)));
-    PT_HIP(c, hipMalloc((void **)&c->d_sphere_material, h_sm.size() * sizeof(int32_t)));
-    PT_HIP(c, hipMalloc((void **)&c->d_mat_a, h_mat_a.size() * sizeof(float4)));
-    PT_HIP(c, hipMalloc((void **)&c->d_mat_b, h_mat_b.size() * sizeof(int2)));
+    PT_HIP(c, hipMalloc((void **)&c->d_shade_a, h_shade_a.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_shade_b, h_shade_b.size() * sizeof(int2)));
     PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_spheres, h_spheres.data(), h_spheres.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemcpy(c->d_sphere_material, h_sm.data(), h_sm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemcpy(c->d_mat_a, h_mat_a.data(), h_mat_a.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemcpy(c->d_mat_b, h_mat_b.data(), h_mat_b.size() * sizeof(int2), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_shade_a, h_shade_a.data(), h_shade_a.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_shade_b, h_shade_b.data(), h_shade_b.size() * sizeof(int2), hipMemcpyHostToDevice));
     if (n_textures > 0) {
         std::vector<ptd::Texture> h_tex((size_t)n_textures);
         for (int32_t i = 0; i < n_textures; i++) {
@@ -316,12 +313,12 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     }
     c->scene.nodes = c->d_nodes;
     c->scene.spheres = c->d_spheres;
-    c->scene.sphere_material = c->d_sphere_material;
-    c->scene.mat_a = c->d_mat_a;
-    c->scene.mat_b = c->d_mat_b;
+    c->scene.shade_a = c->d_shade_a;
+    c->scene.shade_b = c->d_shade_b;
     c->scene.textures = c->d_textures;
     c->scene.n_nodes = n_nodes;
     c->scene.n_spheres = n_spheres;
+    c->scene.root_code = code_of(0);
     c->have_scene = true;
     return PT_OK;
 }

@@ -146,13 +146,13 @@ PTD float p_asinf(float y)
 // ---- device scene -------------------------------------------------------------
 struct Texture { const uint8_t *rgb8; int32_t width, height; };
 struct Scene {
-    const float4 *nodes;     // 2 x float4 per node, DFS pre-order (layout: pt_kernels.hip)
-    const float4 *spheres;   // (cx, cy, cz, radius), Scene::add order
-    const int32_t *sphere_material;
-    const float4 *mat_a;     // (albedo r, g, b, param)
-    const int2 *mat_b;       // (kind, texture index or -1)
+    const float4 *nodes;     // 2 x float4 per node, DFS pre-order (layout below)
+    const float4 *spheres;   // per primitive: (cx, cy, cz, radius), Scene::add order
+    const float4 *shade_a;   // per primitive: its material's (albedo r, g, b, param)
+    const int2 *shade_b;     // per primitive: its material's (kind, texture index or -1)
     const Texture *textures;
     int32_t n_nodes, n_spheres;
+    int32_t root_code;       // node code of node 0
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;
@@ -197,64 +197,72 @@ PTD f3 sphere_uv_color(const Scene &sc, int tex, f3 n)                          
 
 // ---- Scene::trace (scene/mod.rs:24-34) over the flattened BvhNode tree ---------
 //
-// Node i occupies nodes[2i], nodes[2i+1]:
-//   Split: (bmin.x, bmin.y, bmin.z, bits(skip)) (bmax.x, bmax.y, bmax.z, bits(-1))
-//   Leaf : (c.x,    c.y,    c.z,    r*r)        (unused, unused, unused, bits(prim))
-// The walk is the iterative form of BvhNode::trace (bvh.rs:106-127): DFS pre-order,
-// left before right, max_t = closest hit so far; a Split is entered only if its
-// own box passes AABB::intersect (aabb.rs:25-36); a Leaf is traced without a box
-// test (bvh.rs:109); strict '<' keeps the first hit in DFS order on ties
-// (sphere.rs:57,63).
+// A node CODE is its index in DFS pre-order with the sign bit set when the node
+// is a Leaf; the code n_nodes (no flag) ends the walk.  Node i occupies
+// nodes[2i], nodes[2i+1]:
+//   Split: (bmin.x, bmin.y, bmin.z, bits(skip code))  (bmax.x, bmax.y, bmax.z, bits(code of i+1))
+//   Leaf : (c.x,    c.y,    c.z,    r*r)              (-, -, bits(prim), bits(code of i+1))
+// so the kind of the NEXT node is known before its data arrives.  The walk is the
+// iterative form of BvhNode::trace (bvh.rs:106-127): DFS pre-order, left before
+// right, max_t = closest hit so far; a Split is entered only if its own box
+// passes AABB::intersect (aabb.rs:25-36); a Leaf is traced without a box test
+// (bvh.rs:109); strict '<' keeps the first hit in DFS order on ties (sphere.rs:57,63).
 //
 // REGULAR = every component of origin and of 1/direction is finite.  Then no
 // operand of the slab test can be NaN and IEEE min/max (one v_min/v_max each)
 // give the same tmin/tmax as the reference's _mm_min_ps/_mm_max_ps; the general
 // variant reproduces the SSE "second operand on NaN" rule explicitly.
+constexpr float T_MIN = 0.001f;                                                  // scene/mod.rs:25
+constexpr float T_MAX = 3.402823466e+38f;                                        // f32::MAX, scene/mod.rs:27
+constexpr int32_t LEAF_BIT = (int32_t)0x80000000;
+
 struct Hit { float t; int32_t prim; };
 
+PTD int code_index(int32_t code) { return code & 0x7fffffff; }
+
+// One-instruction IEEE min/max.  Only used where no operand can be NaN (REGULAR
+// rays), where they equal both _mm_min_ps/_mm_max_ps and Rust's f32::min/max;
+// the builtins would add a canonicalising v_max(x, x) per operand.
+PTD float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PTD float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PTD float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+PTD float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// AABB::intersect (aabb.rs:25-36) for the Split whose data is (n0, n1); returns the next code
 template <bool REGULAR>
-PTD Hit traverse(const Scene &sc, const Ray &ray, f3 inv)
+PTD int32_t split_step(const float4 n0, const float4 n1, const f3 o, const f3 inv, const float closest)
 {
-    const float T_MIN = 0.001f;
-    Hit h; h.t = 3.402823466e+38f; h.prim = -1;
-    const float a = dot(ray.d, ray.d);                                           // sphere.rs:49
-    int idx = 0;
-    const int n = sc.n_nodes;
-    while (idx < n) {
-        const float4 n0 = sc.nodes[2 * idx], n1 = sc.nodes[2 * idx + 1];
-        const int prim = __float_as_int(n1.w);
-        if (prim < 0) {                                                          // Split: aabb.rs:25-36
-            f3 v0 = (mk(n0.x, n0.y, n0.z) - ray.o) * inv;
-            f3 v1 = (mk(n1.x, n1.y, n1.z) - ray.o) * inv;
-            float mnx, mny, mnz, mxx, mxy, mxz;
-            if (REGULAR) {
-                mnx = __builtin_fminf(v0.x, v1.x); mny = __builtin_fminf(v0.y, v1.y); mnz = __builtin_fminf(v0.z, v1.z);
-                mxx = __builtin_fmaxf(v0.x, v1.x); mxy = __builtin_fmaxf(v0.y, v1.y); mxz = __builtin_fmaxf(v0.z, v1.z);
-            } else {
-                mnx = sse_min(v0.x, v1.x); mny = sse_min(v0.y, v1.y); mnz = sse_min(v0.z, v1.z);
-                mxx = sse_max(v0.x, v1.x); mxy = sse_max(v0.y, v1.y); mxz = sse_max(v0.z, v1.z);
-            }
-            float tmin = __builtin_fmaxf(T_MIN, __builtin_fmaxf(mnx, __builtin_fmaxf(mny, mnz)));
-            float tmax = __builtin_fminf(h.t, __builtin_fminf(mxx, __builtin_fminf(mxy, mxz)));
-            idx = (tmin < tmax) ? idx + 1 : __float_as_int(n0.w);
-        } else {                                                                 // Leaf: sphere.rs:46-69
-            f3 oc = ray.o - mk(n0.x, n0.y, n0.z);
-            float b = dot(oc, ray.d);
-            float c = dot(oc, oc) - n0.w;
-            float d = b * b - a * c;
-            if (d > 0.0f) {
-                float sq = __builtin_sqrtf(d);
-                float sol = (-b - sq) / a;
-                if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = prim; }
-                else {
-                    sol = (-b + sq) / a;
-                    if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = prim; }
-                }
-            }
-            idx = idx + 1;
+    f3 v0 = (mk(n0.x, n0.y, n0.z) - o) * inv;
+    f3 v1 = (mk(n1.x, n1.y, n1.z) - o) * inv;
+    float tmin, tmax;
+    if (REGULAR) {
+        tmin = vmax3(vmin(v0.x, v1.x), vmin(v0.y, v1.y), vmax(vmin(v0.z, v1.z), T_MIN));
+        tmax = vmin3(vmax(v0.x, v1.x), vmax(v0.y, v1.y), vmin(vmax(v0.z, v1.z), closest));
+    } else {
+        float mnx = sse_min(v0.x, v1.x), mny = sse_min(v0.y, v1.y), mnz = sse_min(v0.z, v1.z);
+        float mxx = sse_max(v0.x, v1.x), mxy = sse_max(v0.y, v1.y), mxz = sse_max(v0.z, v1.z);
+        tmin = __builtin_fmaxf(T_MIN, __builtin_fmaxf(mnx, __builtin_fmaxf(mny, mnz)));
+        tmax = __builtin_fminf(closest, __builtin_fminf(mxx, __builtin_fminf(mxy, mxz)));
+    }
+    return (tmin < tmax) ? __float_as_int(n1.w) : __float_as_int(n0.w);
+}
+
+// Sphere::trace (sphere.rs:46-69) for the Leaf whose data is (n0, n1); `a` = dot(d, d)
+PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, const float a, Hit &h)
+{
+    f3 oc = o - mk(n0.x, n0.y, n0.z);
+    float b = dot(oc, d);
+    float c = dot(oc, oc) - n0.w;
+    float disc = b * b - a * c;
+    if (disc > 0.0f) {
+        float sq = __builtin_sqrtf(disc);
+        float sol = (-b - sq) / a;
+        if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
+        else {
+            sol = (-b + sq) / a;
+            if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
         }
     }
-    return h;
 }
 
 PTD bool finite3(f3 v)
@@ -262,11 +270,22 @@ PTD bool finite3(f3 v)
     return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z);
 }
 
+// whole-ray walk (used by the primary-hit kernel; the path kernel runs the same
+// steps from its state machine)
 PTD Hit scene_trace(const Scene &sc, const Ray &ray)
 {
-    f3 inv = fill(1.0f) / ray.d;                                                 // scene/mod.rs:31
-    if (finite3(inv) && finite3(ray.o)) return traverse<true>(sc, ray, inv);
-    return traverse<false>(sc, ray, inv);
+    const f3 inv = fill(1.0f) / ray.d;                                           // scene/mod.rs:31
+    const bool regular = finite3(inv) && finite3(ray.o);
+    const float a = dot(ray.d, ray.d);                                           // sphere.rs:49
+    Hit h; h.t = T_MAX; h.prim = -1;
+    int32_t code = sc.root_code;
+    while (code_index(code) < sc.n_nodes) {
+        const int i = code_index(code);
+        const float4 n0 = sc.nodes[2 * i], n1 = sc.nodes[2 * i + 1];
+        if (code < 0) { leaf_step(n0, n1, ray.o, ray.d, a, h); code = __float_as_int(n1.w); }
+        else code = regular ? split_step<true>(n0, n1, ray.o, inv, h.t) : split_step<false>(n0, n1, ray.o, inv, h.t);
+    }
+    return h;
 }
 
 // ---- Material::scatter (material/*.rs) -----------------------------------------
@@ -274,9 +293,8 @@ PTD Hit scene_trace(const Scene &sc, const Ray &ray)
 PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
 {
     const float4 sp = sc.spheres[h.prim];
-    const int m = sc.sphere_material[h.prim];
-    const float4 ma = sc.mat_a[m];
-    const int2 mb = sc.mat_b[m];
+    const float4 ma = sc.shade_a[h.prim];
+    const int2 mb = sc.shade_b[h.prim];
     // Sphere::record (sphere.rs:37-42)
     const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
     const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));

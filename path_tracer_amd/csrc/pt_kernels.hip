@@ -30,10 +30,39 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 // K2.  The replacement for the tile loop of ParallelRenderer::render
 // (src/parallel_renderer/mod.rs:155-203) + Raytracer::render_fragment
 // (src/raytracer.rs:98-123): the grid covers the frame, each lane owns one pixel
-// and a contiguous chunk of its sample indices and walks them in order.  The
-// sample loop and the bounce loop of trace_pixel / trace_ray are flattened into
-// ONE loop whose body is one path segment: a lane whose path ends starts its
-// next sample at once instead of idling until the longest path of the wave ends.
+// and a contiguous chunk of its sample indices and walks them IN ORDER, so the
+// per-pixel fp32 sum is the reference's (raytracer.rs:88).
+//
+// The three nested loops of the reference (samples, bounces, BVH nodes) are
+// flattened into ONE loop over a per-lane state machine.  Every iteration the
+// wave votes (ballot + popcount, scalar) for the state most lanes are in and runs
+// only that state's step, predicated on the lanes in it:
+//   SPLIT  one AABB::intersect of the walk           (aabb.rs:25-36)
+//   LEAF   one Sphere::trace of the walk             (sphere.rs:46-69)
+//   HIT    Sphere::record + Material::scatter        (sphere.rs:37-42, material/*.rs)
+//   END    sky, accumulate, next sample's camera ray (raytracer.rs:67-70,88,77-85)
+// A lane whose path or walk ends never idles until the longest one of the wave
+// ends, and box tests / sphere tests / shading are not serialised against each
+// other inside one iteration.  Each lane still executes exactly the reference's
+// operation sequence for its pixel, so results do not depend on the vote.
+#ifndef PT_SPLIT_DROP
+#define PT_SPLIT_DROP 2   // a SPLIT run ends once a quarter of its lanes have left the state
+#endif
+#ifndef PT_W_SPLIT
+#define PT_W_SPLIT 1
+#endif
+#ifndef PT_W_LEAF
+#define PT_W_LEAF 1
+#endif
+#ifndef PT_W_HIT
+#define PT_W_HIT 1
+#endif
+#ifndef PT_W_END
+#define PT_W_END 1
+#endif
+
+enum : int { ST_SPLIT = 0, ST_LEAF = 1, ST_HIT = 2, ST_END = 3, ST_DONE = 4 };
+
 __global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderParams rp, float *__restrict__ radiance)
 {
     __shared__ float part[3 * 64];
@@ -60,42 +89,110 @@ __global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderPa
         sum = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
 
     const int S = rp.S;
+    const int n_nodes = sc.n_nodes;
+
+    // per-lane state.  `code` is the node the walk stands on (pt_device.hpp); the
+    // state of a walking lane is read off it: SPLIT, LEAF, or walk finished.
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
+    f3 inv = fill(0.0f);
+    float a = 0.0f;
+    Hit h; h.t = T_MAX; h.prim = -1;
+    int32_t code = 0;
     f3 att = fill(1.0f);
     int bounce = 0;
     uint64_t rng = 0;
-    bool alive = false;
+    bool regular = true, to_sky = true;
+    int state = ST_DONE;
 
-    for (;;) {
-        if (!alive) {
-            if (s >= s_end) break;
-            ray = sample_ray(cam, S, px, py, s);                                 // raytracer.rs:77-85
-            att = fill(1.0f);                                                    // raytracer.rs:50
-            bounce = 0;
-            rng = path_rng(rp.seed, pixel, (uint32_t)s);
-            alive = true;
+    // stand on node `c`: end of walk -> HIT / END
+    auto enter = [&](int32_t c) {
+        code = c;
+        if (code_index(c) >= n_nodes) {
+            state = h.prim >= 0 ? ST_HIT : ST_END;
+            to_sky = true;
+        } else {
+            state = c < 0 ? ST_LEAF : ST_SPLIT;
         }
-        // one iteration of the `for _ in 0..MAX_TRACES` loop (raytracer.rs:52-65)
-        const Hit h = scene_trace(sc, ray);
-        bool to_sky = true;
-        bool done = true;
-        f3 color = fill(0.0f);
-        if (h.prim >= 0) {
-            f3 a; Ray nr;
-            if (scatter(sc, ray, h, rng, a, nr)) {
-                att = att * a;                                                   // raytracer.rs:57
-                ray = nr;
-                bounce++;
-                done = bounce >= 5;                                              // MAX_TRACES, raytracer.rs:48
-            } else {
-                to_sky = false;                                                  // raytracer.rs:60: return 0
+    };
+    auto count = [&](int st) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(state == st))); };
+
+    // SPLIT and LEAF steps go straight back to the vote; HIT and END fall through to
+    // the shared tails: new_path -> the next sample's camera ray (or DONE),
+    // new_walk -> Scene::trace prologue (scene/mod.rs:24-34) and enter(root).
+    bool new_path = true, new_walk = false;
+    for (;;) {
+        if (new_path) {
+            if (s >= s_end) state = ST_DONE;
+            else {
+                ray = sample_ray(cam, S, px, py, s);                             // raytracer.rs:77-85
+                att = fill(1.0f);                                                // raytracer.rs:50
+                bounce = 0;
+                rng = path_rng(rp.seed, pixel, (uint32_t)s);
+                new_walk = true;
             }
         }
-        if (done) {
-            if (to_sky) color = sky(ray, att);                                   // raytracer.rs:67-70
-            sum = sum + color;                                                   // raytracer.rs:88
-            s++;
-            alive = false;
+        if (new_walk) {
+            inv = fill(1.0f) / ray.d;                                            // scene/mod.rs:31
+            regular = finite3(inv) && finite3(ray.o);
+            a = dot(ray.d, ray.d);                                               // sphere.rs:49
+            h.t = T_MAX; h.prim = -1;
+            enter(sc.root_code);
+        }
+        new_path = false; new_walk = false;
+
+        int pick;
+        for (;;) {
+            const int cS = count(ST_SPLIT), cL = count(ST_LEAF), cH = count(ST_HIT), cE = count(ST_END);
+            int top = cS * PT_W_SPLIT, v;
+            pick = ST_SPLIT;
+            v = cL * PT_W_LEAF; if (v > top) { top = v; pick = ST_LEAF; }
+            v = cH * PT_W_HIT;  if (v > top) { top = v; pick = ST_HIT; }
+            v = cE * PT_W_END;  if (v > top) { top = v; pick = ST_END; }
+            if (top == 0) pick = ST_DONE;
+            if (pick == ST_SPLIT) {
+                const bool all_regular = __ballot(state == ST_SPLIT && !regular) == 0ull;
+                const int keep = cS - (cS >> PT_SPLIT_DROP);   // leave when this many lanes have left SPLIT
+                do {
+                    if (state == ST_SPLIT) {
+                        const int i = code_index(code);
+                        const float4 n0 = sc.nodes[2 * i], n1 = sc.nodes[2 * i + 1];
+                        enter(all_regular ? split_step<true>(n0, n1, ray.o, inv, h.t)
+                                          : split_step<false>(n0, n1, ray.o, inv, h.t));
+                    }
+                } while (count(ST_SPLIT) >= keep && keep > 0);
+            } else if (pick == ST_LEAF) {
+                if (state == ST_LEAF) {
+                    const int i = code_index(code);
+                    const float4 n0 = sc.nodes[2 * i], n1 = sc.nodes[2 * i + 1];
+                    leaf_step(n0, n1, ray.o, ray.d, a, h);
+                    enter(__float_as_int(n1.w));
+                }
+            } else break;
+        }
+        if (pick == ST_DONE) break;
+
+        if (pick == ST_HIT) {
+            if (state == ST_HIT) {
+                // one hit iteration of `for _ in 0..MAX_TRACES` (raytracer.rs:52-61)
+                f3 am; Ray nr;
+                if (scatter(sc, ray, h, rng, am, nr)) {
+                    att = att * am;                                              // raytracer.rs:57
+                    ray = nr;
+                    bounce++;
+                    if (bounce >= 5) { state = ST_END; to_sky = true; }          // MAX_TRACES, raytracer.rs:48
+                    else new_walk = true;
+                } else {
+                    state = ST_END; to_sky = false;                              // raytracer.rs:60: return 0
+                }
+            }
+        } else {
+            if (state == ST_END) {
+                f3 color = fill(0.0f);
+                if (to_sky) color = sky(ray, att);                               // raytracer.rs:67-70
+                sum = sum + color;                                               // raytracer.rs:88
+                s++;
+                new_path = true;
+            }
         }
     }
 
