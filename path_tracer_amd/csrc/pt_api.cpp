@@ -20,6 +20,9 @@ thread_local std::string g_create_error;
 // lanes needed to give every SIMD of the chip a full complement of waves:
 // 256 CU x 4 SIMD x 8 waves x 64 lanes (MI355X_MICROARCH.md "Chip-level parameters")
 constexpr int64_t kFullChipLanes = 256ll * 4 * 8 * 64;
+// n0[] entries (16 B each) a workgroup stages in LDS: 16 KiB, so LDS (160 KiB per CU)
+// never limits residency below the 8 workgroups x 4 waves a CU can hold
+constexpr int32_t kMaxLdsNodes = 1024;
 
 }  // namespace
 
@@ -245,13 +248,24 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
         if (nd.prim < 0 && i + 1 >= n_nodes) return fail(c, PT_ERR_INVALID, "node %d: split without children", i);
     }
 
-    // device layout (pt_device.hpp): node codes carry the kind of the node they name
-    auto code_of = [&](int32_t i) -> int32_t {
-        return (i < n_nodes && nodes[i].prim >= 0) ? (int32_t)(i | 0x80000000u) : i;
-    };
+    // a Split's children: left = i + 1, right = the node after the left subtree; both
+    // subtrees must end where the Split's own subtree ends (proper nesting)
+    for (int32_t i = 0; i < n_nodes; i++) {
+        if (nodes[i].prim >= 0) continue;
+        const int32_t r = nodes[i + 1].skip;
+        if (r >= nodes[i].skip || nodes[r].skip != nodes[i].skip)
+            return fail(c, PT_ERR_INVALID, "node %d: children do not tile its subtree", i);
+    }
+
+    // Device layout (pt_device.hpp).  Nodes are renumbered breadth-first so that the
+    // top of the tree -- visited by every ray -- is the prefix the path kernel keeps
+    // in LDS; the walk order is unchanged, it follows the explicit next/skip codes.
+    std::vector<int32_t> slot, order;
     std::vector<float4> h_nodes, h_spheres, h_shade_a;
     std::vector<int2> h_shade_b;
     try {
+        slot.resize((size_t)n_nodes);
+        order.reserve((size_t)n_nodes);
         h_nodes.resize(2 * (size_t)n_nodes);
         h_spheres.resize((size_t)n_spheres);
         h_shade_a.resize((size_t)n_spheres);
@@ -259,6 +273,19 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
+    order.push_back(0);
+    for (size_t q = 0; q < order.size(); q++) {
+        const int32_t i = order[q];
+        slot[i] = (int32_t)q;
+        if (nodes[i].prim < 0) { order.push_back(i + 1); order.push_back(nodes[i + 1].skip); }
+    }
+    if ((int32_t)order.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
+    // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
+    auto code_of = [&](int32_t i) -> int32_t {
+        if (i >= n_nodes) return n_nodes;
+        return nodes[i].prim >= 0 ? (int32_t)((uint32_t)slot[i] | 0x80000000u) : slot[i];
+    };
+    float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_nodes;
     for (int32_t i = 0; i < n_nodes; i++) {
         const pt_bvh_node &nd = nodes[i];
         float4 a, b;
@@ -275,8 +302,8 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
             std::memcpy(&b.z, &nd.prim, 4);
         }
         std::memcpy(&b.w, &next, 4);
-        h_nodes[2 * (size_t)i] = a;
-        h_nodes[2 * (size_t)i + 1] = b;
+        h_n0[slot[i]] = a;
+        h_n1[slot[i]] = b;
     }
     for (int32_t i = 0; i < n_spheres; i++) {
         const pt_material &m = materials[spheres[i].material];
@@ -311,7 +338,8 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
         PT_HIP(c, hipMalloc((void **)&c->d_textures, h_tex.size() * sizeof(ptd::Texture)));
         PT_HIP(c, hipMemcpy(c->d_textures, h_tex.data(), h_tex.size() * sizeof(ptd::Texture), hipMemcpyHostToDevice));
     }
-    c->scene.nodes = c->d_nodes;
+    c->scene.n0 = c->d_nodes;
+    c->scene.n1 = c->d_nodes + n_nodes;
     c->scene.spheres = c->d_spheres;
     c->scene.shade_a = c->d_shade_a;
     c->scene.shade_b = c->d_shade_b;
@@ -319,6 +347,7 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     c->scene.n_nodes = n_nodes;
     c->scene.n_spheres = n_spheres;
     c->scene.root_code = code_of(0);
+    c->scene.lds_nodes = n_nodes < kMaxLdsNodes ? n_nodes : kMaxLdsNodes;
     c->have_scene = true;
     return PT_OK;
 }

@@ -146,13 +146,14 @@ PTD float p_asinf(float y)
 // ---- device scene -------------------------------------------------------------
 struct Texture { const uint8_t *rgb8; int32_t width, height; };
 struct Scene {
-    const float4 *nodes;     // 2 x float4 per node, DFS pre-order (layout below)
+    const float4 *n0, *n1;   // one float4 each per node (layout below)
     const float4 *spheres;   // per primitive: (cx, cy, cz, radius), Scene::add order
     const float4 *shade_a;   // per primitive: its material's (albedo r, g, b, param)
     const int2 *shade_b;     // per primitive: its material's (kind, texture index or -1)
     const Texture *textures;
     int32_t n_nodes, n_spheres;
-    int32_t root_code;       // node code of node 0
+    int32_t root_code;       // node code of the root
+    int32_t lds_nodes;       // n0[0 .. lds_nodes) is staged in LDS by the path kernel
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;
@@ -197,12 +198,15 @@ PTD f3 sphere_uv_color(const Scene &sc, int tex, f3 n)                          
 
 // ---- Scene::trace (scene/mod.rs:24-34) over the flattened BvhNode tree ---------
 //
-// A node CODE is its index in DFS pre-order with the sign bit set when the node
-// is a Leaf; the code n_nodes (no flag) ends the walk.  Node i occupies
-// nodes[2i], nodes[2i+1]:
-//   Split: (bmin.x, bmin.y, bmin.z, bits(skip code))  (bmax.x, bmax.y, bmax.z, bits(code of i+1))
-//   Leaf : (c.x,    c.y,    c.z,    r*r)              (-, -, bits(prim), bits(code of i+1))
-// so the kind of the NEXT node is known before its data arrives.  The walk is the
+// A node CODE is the node's slot in the arrays n0[], n1[] with the sign bit set
+// when the node is a Leaf; the code n_nodes (no flag) ends the walk.  Slots are
+// numbered breadth-first (top of the tree first); the walk does not depend on
+// the numbering, it follows the codes stored in the nodes:
+//          n0[slot]                                   n1[slot]
+//   Split: (bmin.x, bmin.y, bmin.z, bits(skip code))  (bmax.x, bmax.y, bmax.z, bits(next code))
+//   Leaf : (c.x,    c.y,    c.z,    r*r)              (-, -, bits(prim), bits(next code))
+// next = the following node in DFS pre-order, skip = the first node after this
+// node's subtree, so the kind of the NEXT node is known before its data arrives.  The walk is the
 // iterative form of BvhNode::trace (bvh.rs:106-127): DFS pre-order, left before
 // right, max_t = closest hit so far; a Split is entered only if its own box
 // passes AABB::intersect (aabb.rs:25-36); a Leaf is traced without a box test
@@ -228,7 +232,15 @@ PTD float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r)
 PTD float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 PTD float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// AABB::intersect (aabb.rs:25-36) for the Split whose data is (n0, n1); returns the next code
+PTD float vmed3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// AABB::intersect (aabb.rs:25-36) for the Split whose data is (n0, n1); returns the next code.
+// REGULAR (no NaN anywhere): with lo_k = min(v0.k, v1.k), hi_k = max(v0.k, v1.k) the test is
+//   max(T_MIN, lo_x, lo_y, lo_z) < min(closest, hi_x, hi_y, hi_z).
+// The chains e = med3(med3(med3(T_MIN, x), y), z), f = med3(med3(med3(closest, x), y), z)
+// (med3(e, v0.k, v1.k) = clamp e into [lo_k, hi_k]) give the same e < f DECISION for every
+// ordering of the eight values -- checked exhaustively over all weak orders of 8 elements
+// (tests/test_host_logic.py::test_med3_slab_identity) -- with 6 half-rate VALU ops instead of 10.
 template <bool REGULAR>
 PTD int32_t split_step(const float4 n0, const float4 n1, const f3 o, const f3 inv, const float closest)
 {
@@ -236,8 +248,8 @@ PTD int32_t split_step(const float4 n0, const float4 n1, const f3 o, const f3 in
     f3 v1 = (mk(n1.x, n1.y, n1.z) - o) * inv;
     float tmin, tmax;
     if (REGULAR) {
-        tmin = vmax3(vmin(v0.x, v1.x), vmin(v0.y, v1.y), vmax(vmin(v0.z, v1.z), T_MIN));
-        tmax = vmin3(vmax(v0.x, v1.x), vmax(v0.y, v1.y), vmin(vmax(v0.z, v1.z), closest));
+        tmin = vmed3(vmed3(vmed3(T_MIN, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
+        tmax = vmed3(vmed3(vmed3(closest, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
     } else {
         float mnx = sse_min(v0.x, v1.x), mny = sse_min(v0.y, v1.y), mnz = sse_min(v0.z, v1.z);
         float mxx = sse_max(v0.x, v1.x), mxy = sse_max(v0.y, v1.y), mxz = sse_max(v0.z, v1.z);
@@ -281,7 +293,7 @@ PTD Hit scene_trace(const Scene &sc, const Ray &ray)
     int32_t code = sc.root_code;
     while (code_index(code) < sc.n_nodes) {
         const int i = code_index(code);
-        const float4 n0 = sc.nodes[2 * i], n1 = sc.nodes[2 * i + 1];
+        const float4 n0 = sc.n0[i], n1 = sc.n1[i];
         if (code < 0) { leaf_step(n0, n1, ray.o, ray.d, a, h); code = __float_as_int(n1.w); }
         else code = regular ? split_step<true>(n0, n1, ray.o, inv, h.t) : split_step<false>(n0, n1, ray.o, inv, h.t);
     }

@@ -63,17 +63,34 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 
 enum : int { ST_SPLIT = 0, ST_LEAF = 1, ST_HIT = 2, ST_END = 3, ST_DONE = 4 };
 
-__global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderParams rp, float *__restrict__ radiance)
+// Workgroup = 4 waves that share one LDS copy of n0[0 .. lds_nodes) (the top of the
+// tree, breadth-first) and are otherwise independent: one tile each.  n1[] is read
+// through the vector L1, so a node visit puts one 16-byte access on each of the two
+// memory pipes of the CU instead of two on the L1 (the measured bottleneck:
+// profiles/r01).
+constexpr int WAVES_PER_GROUP = 4;
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 8   // waves per SIMD the register allocator must leave room for (64 VGPRs)
+#endif
+
+template <bool ALL_IN_LDS>
+__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, int n_tiles,
+                                                                    float *__restrict__ radiance)
 {
-    __shared__ float part[3 * 64];
-    const int lane = threadIdx.x;
+    extern __shared__ float4 lds_n0[];
+    const int lds_nodes = sc.lds_nodes;
+    for (int i = threadIdx.x; i < lds_nodes; i += 64 * WAVES_PER_GROUP) lds_n0[i] = sc.n0[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * WAVES_PER_GROUP + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
     const int L = rp.lanes;
     const int P = 64 / L;
     int tw, th;
     tile_shape(L, tw, th);
     const int slot = lane % P, chunk = lane / P;
     const int tiles_x = (cam.width + tw - 1) / tw;
-    const int tile = blockIdx.x;
     const int px = (tile % tiles_x) * tw + slot % tw;
     const int py = (tile / tiles_x) * th + slot / tw;
     const bool valid = px < cam.width && py < cam.height;
@@ -91,38 +108,39 @@ __global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderPa
     const int S = rp.S;
     const int n_nodes = sc.n_nodes;
 
-    // per-lane state.  `code` is the node the walk stands on (pt_device.hpp); the
-    // state of a walking lane is read off it: SPLIT, LEAF, or walk finished.
+    // Per-lane state.  `code` is the whole control state of the lane: a node code while
+    // the walk stands on a node (Split: [0, n_nodes), Leaf: sign bit set), n_nodes when
+    // the walk has just ended, and three values above it for the other states.
+    const int32_t C_HIT = n_nodes + 1, C_END = n_nodes + 2, C_DONE = n_nodes + 3;
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
     f3 inv = fill(0.0f);
     float a = 0.0f;
     Hit h; h.t = T_MAX; h.prim = -1;
-    int32_t code = 0;
+    int32_t code = C_DONE;
     f3 att = fill(1.0f);
     int bounce = 0;
     uint64_t rng = 0;
     bool regular = true, to_sky = true;
-    int state = ST_DONE;
 
-    // stand on node `c`: end of walk -> HIT / END
-    auto enter = [&](int32_t c) {
-        code = c;
-        if (code_index(c) >= n_nodes) {
-            state = h.prim >= 0 ? ST_HIT : ST_END;
-            to_sky = true;
-        } else {
-            state = c < 0 ? ST_LEAF : ST_SPLIT;
-        }
+    const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, n_nodes * 16, 0x00020000);
+    // n1[i] through the L1 (one 32-bit byte offset serves both arrays), n0[i] from LDS when staged
+    auto fetch = [&](int32_t c, float4 &n0, float4 &n1) {
+        const int off = code_index(c) << 4;
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(n1_rsrc, off, 0, 0);
+        n1 = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+        if (ALL_IN_LDS) n0 = *(const float4 *)((const char *)lds_n0 + off);
+        else if (off < (lds_nodes << 4)) { n0 = *(const float4 *)((const char *)lds_n0 + off); asm volatile("" : "+v"(n0.x)); }
+        else n0 = *(const float4 *)((const char *)sc.n0 + off);
     };
-    auto count = [&](int st) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(state == st))); };
+    auto lanes = [&](bool p) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(p))); };
 
     // SPLIT and LEAF steps go straight back to the vote; HIT and END fall through to
     // the shared tails: new_path -> the next sample's camera ray (or DONE),
-    // new_walk -> Scene::trace prologue (scene/mod.rs:24-34) and enter(root).
+    // new_walk -> Scene::trace prologue (scene/mod.rs:24-34), standing on the root.
     bool new_path = true, new_walk = false;
     for (;;) {
         if (new_path) {
-            if (s >= s_end) state = ST_DONE;
+            if (s >= s_end) code = C_DONE;
             else {
                 ray = sample_ray(cam, S, px, py, s);                             // raytracer.rs:77-85
                 att = fill(1.0f);                                                // raytracer.rs:50
@@ -136,13 +154,15 @@ __global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderPa
             regular = finite3(inv) && finite3(ray.o);
             a = dot(ray.d, ray.d);                                               // sphere.rs:49
             h.t = T_MAX; h.prim = -1;
-            enter(sc.root_code);
+            code = sc.root_code;
         }
         new_path = false; new_walk = false;
 
         int pick;
         for (;;) {
-            const int cS = count(ST_SPLIT), cL = count(ST_LEAF), cH = count(ST_HIT), cE = count(ST_END);
+            if (code == n_nodes) { code = h.prim >= 0 ? C_HIT : C_END; to_sky = true; }   // walk ended
+            const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
+            const int cH = lanes(code == C_HIT), cE = lanes(code == C_END);
             int top = cS * PT_W_SPLIT, v;
             pick = ST_SPLIT;
             v = cL * PT_W_LEAF; if (v > top) { top = v; pick = ST_LEAF; }
@@ -150,43 +170,45 @@ __global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderPa
             v = cE * PT_W_END;  if (v > top) { top = v; pick = ST_END; }
             if (top == 0) pick = ST_DONE;
             if (pick == ST_SPLIT) {
-                const bool all_regular = __ballot(state == ST_SPLIT && !regular) == 0ull;
+                const bool all_regular = __ballot((uint32_t)code < (uint32_t)n_nodes && !regular) == 0ull;
                 const int keep = cS - (cS >> PT_SPLIT_DROP);   // leave when this many lanes have left SPLIT
+                bool at_split = (uint32_t)code < (uint32_t)n_nodes;
                 do {
-                    if (state == ST_SPLIT) {
-                        const int i = code_index(code);
-                        const float4 n0 = sc.nodes[2 * i], n1 = sc.nodes[2 * i + 1];
-                        enter(all_regular ? split_step<true>(n0, n1, ray.o, inv, h.t)
-                                          : split_step<false>(n0, n1, ray.o, inv, h.t));
+                    if (at_split) {
+                        float4 n0, n1;
+                        fetch(code, n0, n1);
+                        code = all_regular ? split_step<true>(n0, n1, ray.o, inv, h.t)
+                                           : split_step<false>(n0, n1, ray.o, inv, h.t);
                     }
-                } while (count(ST_SPLIT) >= keep && keep > 0);
+                    at_split = (uint32_t)code < (uint32_t)n_nodes;
+                } while (lanes(at_split) >= keep && keep > 0);
             } else if (pick == ST_LEAF) {
-                if (state == ST_LEAF) {
-                    const int i = code_index(code);
-                    const float4 n0 = sc.nodes[2 * i], n1 = sc.nodes[2 * i + 1];
+                if (code < 0) {
+                    float4 n0, n1;
+                    fetch(code, n0, n1);
                     leaf_step(n0, n1, ray.o, ray.d, a, h);
-                    enter(__float_as_int(n1.w));
+                    code = __float_as_int(n1.w);
                 }
             } else break;
         }
         if (pick == ST_DONE) break;
 
         if (pick == ST_HIT) {
-            if (state == ST_HIT) {
+            if (code == C_HIT) {
                 // one hit iteration of `for _ in 0..MAX_TRACES` (raytracer.rs:52-61)
                 f3 am; Ray nr;
                 if (scatter(sc, ray, h, rng, am, nr)) {
                     att = att * am;                                              // raytracer.rs:57
                     ray = nr;
                     bounce++;
-                    if (bounce >= 5) { state = ST_END; to_sky = true; }          // MAX_TRACES, raytracer.rs:48
+                    if (bounce >= 5) { code = C_END; to_sky = true; }            // MAX_TRACES, raytracer.rs:48
                     else new_walk = true;
                 } else {
-                    state = ST_END; to_sky = false;                              // raytracer.rs:60: return 0
+                    code = C_END; to_sky = false;                                // raytracer.rs:60: return 0
                 }
             }
         } else {
-            if (state == ST_END) {
+            if (code == C_END) {
                 f3 color = fill(0.0f);
                 if (to_sky) color = sky(ray, att);                               // raytracer.rs:67-70
                 sum = sum + color;                                               // raytracer.rs:88
@@ -200,15 +222,15 @@ __global__ __launch_bounds__(64) void path_kernel(Scene sc, Camera cam, RenderPa
         if (valid) { radiance[3 * pixel] = sum.x; radiance[3 * pixel + 1] = sum.y; radiance[3 * pixel + 2] = sum.z; }
         return;
     }
-    part[3 * lane] = sum.x; part[3 * lane + 1] = sum.y; part[3 * lane + 2] = sum.z;
-    __syncthreads();
+    // lanes_per_pixel > 1: the pixel's chunk sums, added in chunk order by its chunk-0 lane
+    f3 total = fill(0.0f);
+    if (rp.accumulate && chunk == 0 && valid)
+        total = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
+    for (int k = 0; k < L; k++) {
+        const int src = k * P + slot;
+        total = total + mk(__shfl(sum.x, src), __shfl(sum.y, src), __shfl(sum.z, src));
+    }
     if (chunk == 0 && valid) {
-        f3 total = fill(0.0f);
-        if (rp.accumulate) total = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
-        for (int k = 0; k < L; k++) {
-            const int l = k * P + slot;
-            total = total + mk(part[3 * l], part[3 * l + 1], part[3 * l + 2]);
-        }
         radiance[3 * pixel] = total.x; radiance[3 * pixel + 1] = total.y; radiance[3 * pixel + 2] = total.z;
     }
 }
@@ -264,7 +286,14 @@ int tiles_for(const Camera &cam, int lanes)
 hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &rp, float *d_radiance, hipStream_t stream)
 {
     const int tiles = tiles_for(cam, rp.lanes);
-    hipLaunchKernelGGL(path_kernel, dim3(tiles), dim3(64), 0, stream, sc, cam, rp, d_radiance);
+    const int groups = (tiles + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
+    const size_t lds_bytes = (size_t)sc.lds_nodes * sizeof(float4);
+    if (sc.lds_nodes >= sc.n_nodes)
+        hipLaunchKernelGGL(path_kernel<true>, dim3(groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam, rp,
+                           tiles, d_radiance);
+    else
+        hipLaunchKernelGGL(path_kernel<false>, dim3(groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam, rp,
+                           tiles, d_radiance);
     return hipGetLastError();
 }
 
