@@ -399,10 +399,27 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     rp.s1 = sample_end;
     rp.lanes = pick_lanes(c, sample_end - sample_begin);
     rp.accumulate = accumulate ? 1 : 0;
+    rp.stats = nullptr;
+#ifdef PT_STATS
+    static unsigned long long *d_stats = nullptr;
+    if (!d_stats) (void)hipMalloc((void **)&d_stats, 64);
+    (void)hipMemsetAsync(d_stats, 0, 64, st);
+    rp.stats = d_stats;
+#endif
     PT_HIP(c, hipEventRecord(c->ev_start, st));
     PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, d_radiance, st));
     PT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->timed = true;
+#ifdef PT_STATS
+    {
+        unsigned long long hs[8];
+        (void)hipMemcpyAsync(hs, d_stats, 64, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        const char *nm[4] = {"SPLIT", "LEAF", "HIT", "END"};
+        for (int k = 0; k < 4; k++)
+            fprintf(stderr, "[pt stats] %-5s steps %llu  lanes/step %.1f\n", nm[k], hs[2 * k], hs[2 * k] ? (double)hs[2 * k + 1] / hs[2 * k] : 0.0);
+    }
+#endif
     return PT_OK;
 }
 

@@ -137,6 +137,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     // SPLIT and LEAF steps go straight back to the vote; HIT and END fall through to
     // the shared tails: new_path -> the next sample's camera ray (or DONE),
     // new_walk -> Scene::trace prologue (scene/mod.rs:24-34), standing on the root.
+#ifdef PT_STATS
+    unsigned st_n[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};
+#define PT_STAT(k, n) do { st_n[k] += 1; st_l[k] += (n); } while (0)
+#else
+#define PT_STAT(k, n) do { } while (0)
+#endif
     bool new_path = true, new_walk = false;
     for (;;) {
         if (new_path) {
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 const int keep = cS - (cS >> PT_SPLIT_DROP);   // leave when this many lanes have left SPLIT
                 bool at_split = (uint32_t)code < (uint32_t)n_nodes;
                 do {
+                    PT_STAT(0, lanes(at_split));
                     if (at_split) {
                         float4 n0, n1;
                         fetch(code, n0, n1);
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                     at_split = (uint32_t)code < (uint32_t)n_nodes;
                 } while (lanes(at_split) >= keep && keep > 0);
             } else if (pick == ST_LEAF) {
+                PT_STAT(1, cL);
                 if (code < 0) {
                     float4 n0, n1;
                     fetch(code, n0, n1);
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         if (pick == ST_DONE) break;
 
         if (pick == ST_HIT) {
+            PT_STAT(2, lanes(code == C_HIT));
             if (code == C_HIT) {
                 // one hit iteration of `for _ in 0..MAX_TRACES` (raytracer.rs:52-61)
                 f3 am; Ray nr;
@@ -208,6 +217,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 }
             }
         } else {
+            PT_STAT(3, lanes(code == C_END));
             if (code == C_END) {
                 f3 color = fill(0.0f);
                 if (to_sky) color = sky(ray, att);                               // raytracer.rs:67-70
@@ -218,6 +228,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         }
     }
 
+#ifdef PT_STATS
+    if (lane == 0 && rp.stats)
+        for (int k = 0; k < 4; k++) { atomicAdd(&rp.stats[2 * k], (unsigned long long)st_n[k]); atomicAdd(&rp.stats[2 * k + 1], (unsigned long long)st_l[k]); }
+#endif
     if (L == 1) {
         if (valid) { radiance[3 * pixel] = sum.x; radiance[3 * pixel + 1] = sum.y; radiance[3 * pixel + 2] = sum.z; }
         return;

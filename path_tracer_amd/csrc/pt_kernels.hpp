@@ -8,6 +8,7 @@ struct RenderParams {
     int32_t s0, s1;       // sample-index range [s0, s1) rendered by this launch
     int32_t lanes;        // lanes per pixel: power of two in [1, 64]
     int32_t accumulate;   // continue the sum already in the radiance buffer
+    unsigned long long *stats;   // PT_STATS builds only: 8 counters {steps, active lanes} x {SPLIT, LEAF, HIT, END}
 };
 
 namespace ptk {

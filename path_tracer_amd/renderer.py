@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
+from .distributed import shard_range  # noqa: F401  (re-exported)
 from .scene import Camera, Scene
 
 
@@ -141,12 +142,3 @@ class Raytracer:
 
     def pixel_count(self):
         return self.width() * self.height()
-
-
-def shard_range(samples, rank, world):
-    """Sample-index range of `rank` when the samples*samples grid is split over `world` GPUs
-    (contiguous, sizes differ by at most one)."""
-    total = samples * samples
-    base, rem = divmod(total, world)
-    begin = rank * base + min(rank, rem)
-    return begin, begin + base + (1 if rank < rem else 0)

@@ -1,0 +1,184 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports every
+symbol include/pt_amd.h declares, its pure-CPU helpers (BVH build, Camera::new, seeded
+generators) agree bit for bit with the oracle's independent restatements, and errors
+come back as status codes.  No GPU compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import path_tracer_amd as pt
+from path_tracer_amd import _abi
+
+from conftest import MAIN_RS_CAMERA, SCENE_SEED, make_raytracer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
+    lib = pt.lib()                          # binds every signature; AttributeError if one is missing
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_abi.PtSphere) == 20 and C.sizeof(_abi.PtMaterial) == 24
+    assert C.sizeof(_abi.PtBvhNode) == 32 and C.sizeof(_abi.PtCamera) == 56
+    assert C.sizeof(_abi.PtTexture) == 16
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pt.PtError) as e:
+        pt.ParallelRenderer.new(0)
+    assert e.value.code == -4               # PT_ERR_NO_DEVICE
+
+
+def test_camera_matches_oracle(oracle):
+    L = oracle.load()
+    for (w, h, fov) in ((400, 225, 20.0), (1920, 1080, 20.0), (7, 3, 65.5)):
+        cam = pt.Camera.new(width=w, height=h, **dict(MAIN_RS_CAMERA, fov=fov))
+        ref = oracle.OraCamera()
+        L.ora_camera_new(oracle.f3(MAIN_RS_CAMERA["eyes"]), oracle.f3(MAIN_RS_CAMERA["target"]),
+                         oracle.f3(MAIN_RS_CAMERA["up"]), fov, w, h, C.byref(ref))
+        assert bytes(cam.pod) == bytes(ref)
+    bad = _abi.PtCamera()
+    z = (C.c_float * 3)(0, 0, 0)
+    assert pt.lib().pt_camera_look_at(z, z, z, 20.0, 0, 10, C.byref(bad)) == -1
+
+
+@pytest.mark.parametrize("bounds", [pt.RTOW_BOUNDS, (-3, 2, -1, 4), pt.REFERENCE_BOUNDS])
+def test_random_scene_matches_oracle(oracle, bounds):
+    L = oracle.load()
+    need = -L.ora_gen_random_scene(SCENE_SEED, *bounds, None, None, 0)
+    s_ref, m_ref = (oracle.OraSphere * need)(), (oracle.OraMaterial * need)()
+    assert L.ora_gen_random_scene(SCENE_SEED, *bounds, s_ref, m_ref, need) == need
+    s_got, m_got = (_abi.PtSphere * need)(), (_abi.PtMaterial * need)()
+    assert pt.lib().pt_gen_random_scene(SCENE_SEED, *bounds, s_got, m_got, need) == need
+    assert bytes(s_got) == bytes(s_ref) and bytes(m_got) == bytes(m_ref)
+    # too small a buffer reports the size needed
+    assert pt.lib().pt_gen_random_scene(SCENE_SEED, *bounds, s_got, m_got, need - 1) == -need
+    if bounds == pt.REFERENCE_BOUNDS:
+        assert 10000 < need <= 44 * 243 + 4          # generators.rs:42-43: 10,692 candidates + 4
+    if bounds == pt.RTOW_BOUNDS:
+        assert 400 < need <= 22 * 22 + 4
+
+
+def test_random_scene_material_mix(oracle):
+    scene = pt.Scene.new()
+    pt.random_scene(scene, SCENE_SEED, pt.RTOW_BOUNDS)
+    kinds = [type(o.material).__name__ for o in scene.objects]
+    n = len(kinds)
+    assert 0.7 < kinds.count("Lambertian") / n < 0.9      # choose_mat < 0.8 (generators.rs:53)
+    assert 0.08 < kinds.count("Metal") / n < 0.25
+    assert kinds[-3:] == ["Dielectric", "Lambertian", "Metal"]   # generators.rs:72-88
+    assert scene.objects[0].radius == 1000.0
+
+
+def test_simple_scene_matches_oracle(oracle):
+    L = oracle.load()
+    s_ref, m_ref = (oracle.OraSphere * 6)(), (oracle.OraMaterial * 6)()
+    assert L.ora_gen_simple_scene(s_ref, m_ref) == 6
+    s_got, m_got = (_abi.PtSphere * 6)(), (_abi.PtMaterial * 6)()
+    assert pt.lib().pt_gen_simple_scene(s_got, m_got) == 6
+    assert bytes(s_got) == bytes(s_ref) and bytes(m_got) == bytes(m_ref)
+
+
+def test_earthmap_fixture_is_the_decoded_reference_texture():
+    import hashlib
+    tex = pt.PictureTexture.earthmap()
+    assert (tex.width, tex.height) == (1200, 600)
+    assert hashlib.sha256(tex.rgb8.tobytes()).hexdigest().startswith("5bfdb5d86a920e66")
+
+
+@pytest.mark.parametrize("kind", ["simple", "rtow", "reference"])
+def test_bvh_build_matches_oracle(oracle, kind):
+    """pt_bvh_build (prefix/suffix sweep, C++) vs the oracle's literal O(n^2) restatement of
+    bvh.rs:13-91: identical pre-order trees, bit for bit."""
+    rt = make_raytracer(kind, 16, 9, 2)
+    ref = oracle.OracleScene(rt.packed).flatten()
+    assert len(ref) == len(rt.nodes) == 2 * rt.packed.n_spheres - 1
+    assert bytes(ref) == bytes(rt.nodes)
+    prims = sorted(n.prim for n in rt.nodes if n.prim >= 0)
+    assert prims == list(range(rt.packed.n_spheres))        # every sphere is exactly one leaf
+
+
+def test_bvh_build_rejects_bad_arguments():
+    s = (_abi.PtSphere * 2)(_abi.PtSphere(0, 0, 0, 1, 0), _abi.PtSphere(3, 0, 0, 1, 0))
+    out = (_abi.PtBvhNode * 3)()
+    assert pt.lib().pt_bvh_build(s, 2, out, 3) == 3
+    assert pt.lib().pt_bvh_build(s, 2, out, 2) == -5        # PT_ERR_LIMIT
+    assert pt.lib().pt_bvh_build(s, 0, out, 3) == -1        # bvh.rs:19: no objects
+    assert out[0].prim == -1 and out[0].skip == 3 and out[1].prim == 0 and out[2].prim == 1
+
+
+def test_scene_builder_api_mirrors_the_reference():
+    scene = pt.Scene.new()
+    with pytest.raises(ValueError):
+        scene.pack()                                         # "Cannot build BVH without any objects."
+    shared = pt.Metal.new((0.8, 0.6, 0.2), 0.0)
+    scene.add(pt.Sphere.new((0, 0, -1), 0.5, shared))
+    scene.add(pt.Sphere.new((1, 0, -1), 0.5, shared))        # shared Arc<dyn Material>: one entry
+    scene.add(pt.Sphere.new((2, 0, -1), 0.5, pt.Lambertian.new(pt.SolidTexture.new((0.1, 0.2, 0.3)))))
+    tex = pt.PictureTexture.from_rgb8(np.zeros((2, 2, 3), np.uint8))
+    scene.add(pt.Sphere.new((3, 0, -1), 0.5, pt.Lambertian.new(tex)))
+    p = scene.pack()
+    assert (p.n_spheres, p.n_materials, len(p.textures)) == (4, 3, 1)
+    assert [s.material for s in p.spheres] == [0, 0, 1, 2]
+    assert p.materials[1].kind == 0 and p.materials[1].texture == -1 and tuple(p.materials[1].albedo) == pytest.approx((0.1, 0.2, 0.3))
+    assert p.materials[2].texture == 0
+    with pytest.raises(TypeError):
+        scene.add("not a sphere")
+    with pytest.raises(ValueError):
+        pt.Raytracer.new(pt.Camera.new((0, 0, 0), (0, 0, -1), (0, 1, 0), 20.0, 4, 4), scene, 1)   # 0/0 grid
+
+
+def test_shard_range_partitions_the_grid():
+    for samples in (2, 3, 10, 64):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [pt.shard_range(samples, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == samples * samples
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pt.shard_range(4, 2, 2)
+
+
+def test_med3_slab_identity():
+    """The REGULAR slab test of pt_device.hpp uses two med3 chains.  For EVERY weak ordering of
+    the eight values (T_MIN, closest, 3 x (v0, v1)) the decision equals the reference's
+    max(T_MIN, lo_x, lo_y, lo_z) < min(closest, hi_x, hi_y, hi_z).  The operations are
+    order-only, so seven levels already cover most orders; the full 8-level run is in DESIGN.md."""
+    import itertools
+    V = 6
+    g = np.array(list(itertools.product(range(V), repeat=8)), dtype=np.int8)
+    E, Fc, x0, x1, y0, y1, z0, z1 = [g[:, i] for i in range(8)]
+
+    def med3(a, b, c):
+        return np.maximum(np.minimum(a, b), np.minimum(np.maximum(a, b), c))
+    true = np.maximum.reduce([E, np.minimum(x0, x1), np.minimum(y0, y1), np.minimum(z0, z1)]) < \
+        np.minimum.reduce([Fc, np.maximum(x0, x1), np.maximum(y0, y1), np.maximum(z0, z1)])
+    e = med3(med3(med3(E, x0, x1), y0, y1), z0, z1)
+    f = med3(med3(med3(Fc, x0, x1), y0, y1), z0, z1)
+    assert np.array_equal(true, e < f)
+    # and on random floats, including infinities and signed zeros (no NaN: REGULAR rays)
+    rng = np.random.default_rng(0)
+    vals = rng.standard_normal((200000, 8)).astype(np.float32)
+    vals[rng.random(vals.shape) < 0.05] = np.inf
+    vals[rng.random(vals.shape) < 0.05] = -np.inf
+    vals[rng.random(vals.shape) < 0.05] = 0.0
+    vals[rng.random(vals.shape) < 0.05] = -0.0
+    E, Fc, x0, x1, y0, y1, z0, z1 = vals.T
+    true = np.maximum.reduce([E, np.minimum(x0, x1), np.minimum(y0, y1), np.minimum(z0, z1)]) < \
+        np.minimum.reduce([Fc, np.maximum(x0, x1), np.maximum(y0, y1), np.maximum(z0, z1)])
+    e = med3(med3(med3(E, x0, x1), y0, y1), z0, z1)
+    f = med3(med3(med3(Fc, x0, x1), y0, y1), z0, z1)
+    assert np.array_equal(true, e < f)

@@ -1,0 +1,206 @@
+"""Known-answer tests for the CPU oracle (oracle/pt_oracle.c).  The reference has no tests
+(SURVEY.md section 4); every expected value below is derived BY HAND from the cited Rust
+lines, not produced by running the oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+F = np.float32
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(F(x)) for x in v])
+
+
+def test_xorshift64_first_output(oracle):
+    # rng.rs:50-60 from state 1: x ^= x<<13 -> 0x2001; x ^= x>>7 -> 0x2041; x ^= x<<17 -> 0x40822041
+    L = oracle.load()
+    st = C.c_uint64(1)
+    assert L.ora_rng_raw(C.byref(st)) == 0x40822041
+    assert st.value == 0x40822041
+
+
+def test_with_seed_discards_ten(oracle):
+    # rng.rs:27-35: with_seed = ten raw_rand calls
+    L = oracle.load()
+    st = C.c_uint64(0xDEADBEEF)
+    for _ in range(10):
+        L.ora_rng_raw(C.byref(st))
+    assert L.ora_rng_with_seed(0xDEADBEEF) == st.value
+    assert L.ora_rng_with_seed(0) == 0        # 0 is the xorshift fixed point: why path seeds exclude it
+
+
+def test_f32_mapping(oracle):
+    # rng.rs:76-80: ((x as u32) >> 8) as f32 / 2^24.  Check through the generator's own next state.
+    L = oracle.load()
+    for seed in (1, 12345, 2 ** 63 + 7):
+        st = C.c_uint64(seed)
+        probe = C.c_uint64(seed)
+        raw = L.ora_rng_raw(C.byref(probe))
+        got = L.ora_rng_f32(C.byref(st))
+        assert st.value == raw
+        assert got == float(F((raw & 0xFFFFFFFF) >> 8) / F(2 ** 24))
+        assert 0.0 <= got < 1.0
+
+
+def test_path_seed_never_zero_and_distinct(oracle):
+    L = oracle.load()
+    seen = {L.ora_path_seed(7, p, s) for p in range(64) for s in range(64)}
+    assert len(seen) == 64 * 64 and 0 not in seen
+
+
+def test_schlick(oracle):
+    # math/mod.rs:36-45: r0 = ((1-ri)/(1+ri))^2; v = r0 + (1-r0)(1-cos); result v^5 (as written)
+    L = oracle.load()
+    assert L.ora_schlick(0.0, 1.5) == 1.0                      # v = r0 + (1 - r0) = 1
+    r0 = F(F(1.0 - 1.5) / F(1.0 + 1.5))
+    r0 = F(r0 * r0)
+    v = F(r0 + F(F(F(1.0) - r0) * F(0.0)))                     # cos = 1
+    v2 = F(v * v)
+    assert L.ora_schlick(1.0, 1.5) == float(F(F(v2 * v2) * v))
+    assert abs(L.ora_schlick(1.0, 1.5) - 0.04 ** 5) < 1e-12
+
+
+def test_reflect_refract(oracle):
+    L = oracle.load()
+    out = (C.c_float * 3)()
+    L.ora_reflect(f3((1, -1, 0)), f3((0, 1, 0)), out)          # d - 2 (d.n) n
+    assert list(out) == [1.0, 1.0, 0.0]
+    # straight through a flat interface, k = 1: dt = -1, D = 1, refracted = d
+    assert L.ora_refract(f3((0, -1, 0)), f3((0, 1, 0)), 1.0, out) == 1
+    assert list(out) == [0.0, -1.0, 0.0]
+    # total internal reflection: dt = -0.6, D = 1 - 2.25 * 0.64 < 0  (math/mod.rs:29-33)
+    assert L.ora_refract(f3((0.8, -0.6, 0)), f3((0, 1, 0)), 1.5, out) == 0
+
+
+def test_aabb_intersect_inf_and_nan_lanes(oracle):
+    # aabb.rs:25-36 with inv = 1/d = (1, inf, inf)
+    L = oracle.load()
+    box = (f3((0, 0, 0)), f3((1, 1, 1)))
+    big = float(np.finfo(F).max)
+    d = f3((1, 0, 0))
+    assert L.ora_aabb_intersect(*box, f3((-1, 0.5, 0.5)), d, 0.001, big) == 1   # tmin 1 < tmax 2
+    assert L.ora_aabb_intersect(*box, f3((-1, 2.0, 0.5)), d, 0.001, big) == 0   # y slab: [+inf, +inf]
+    assert L.ora_aabb_intersect(*box, f3((-1, 0.5, 0.5)), d, 0.001, 0.5) == 0   # max_t before entry
+    # origin ON a slab plane with a zero direction component: 0 * inf = NaN.
+    #  o.y = bmin.y: v0 = NaN, v1 = +inf -> _mm_min_ps(v0, v1) = v1 = +inf -> tmin = +inf -> miss
+    #  o.y = bmax.y: v0 = -inf, v1 = NaN -> both lanes NaN -> ignored by f32::max/min -> hit
+    assert L.ora_aabb_intersect(*box, f3((-1, 0.0, 0.5)), d, 0.001, big) == 0
+    assert L.ora_aabb_intersect(*box, f3((-1, 1.0, 0.5)), d, 0.001, big) == 1
+
+
+def test_sphere_trace_roots(oracle):
+    # sphere.rs:46-69: c = (0,0,-1), r = 0.5, o = 0, d = (0,0,-1): a = 1, b = -1, c = 0.75, D = 0.25
+    L = oracle.load()
+    out = (C.c_float * 7)()
+    big = float(np.finfo(F).max)
+    args = (f3((0, 0, -1)), 0.5, f3((0, 0, 0)), f3((0, 0, -1)))
+    assert L.ora_sphere_trace(*args, 0.001, big, out) == 1
+    assert list(out) == [0.5, 0.0, 0.0, -0.5, 0.0, 0.0, 1.0]   # near root; n = (0,0,0.5) * 1/sqrt(0.25)
+    assert L.ora_sphere_trace(*args, 0.001, 0.4, out) == 0     # both roots >= max_t
+    assert L.ora_sphere_trace(*args, 0.6, big, out) == 1       # near root <= min_t: far root 1.5
+    assert out[0] == 1.5 and list(out[4:7]) == [0.0, 0.0, -1.0]
+    assert L.ora_sphere_trace(*args, 0.001, 0.5, out) == 0     # strict '<': t == max_t is rejected
+    # a tangent ray has D = 0: `d > 0.0` is false -> miss
+    assert L.ora_sphere_trace(f3((0, 0.5, -1)), 0.5, f3((0, 0, 0)), f3((0, 0, -1)), 0.001, big, out) == 0
+
+
+def test_sphere_uv_and_texture_index(oracle):
+    L = oracle.load()
+    uv = (C.c_float * 2)()
+    L.ora_sphere_uv(f3((1, 0, 0)), uv)                          # phi = 0, theta = 0 (sphere.rs:9-15)
+    assert list(uv) == [0.5, 0.5]
+    L.ora_sphere_uv(f3((0, 1, 0)), uv)                          # pole: atan2(0, 0) = 0, asin(1) = pi/2
+    assert uv[0] == 0.5 and abs(uv[1] - 1.0) < 1e-6
+    L.ora_sphere_uv(f3((0, 1.0002, 0)), uv)                     # |n.y| > 1 -> asin = NaN -> v = NaN
+    assert math.isnan(uv[1])
+    tex = np.arange(4 * 2 * 3, dtype=np.uint8).reshape(2, 4, 3) * 10
+    col = (C.c_float * 3)()
+
+    def color(u, v):
+        L.ora_texture_color(tex.ctypes.data, 4, 2, u, v, col)
+        return [round(c * 255.0) for c in col]
+
+    # picture.rs:21-22: i = (u*4) as i32 = 2; j = ((1-0.5)*2 - 0.001) as i32 = 0
+    assert color(0.5, 0.5) == list(tex[0, 2])
+    assert color(1.0, 0.0) == list(tex[1, 3])                   # i = 4 -> clamp 3; j = 1.999 -> 1
+    assert color(-0.3, 1.0) == list(tex[0, 0])                  # i = -1 -> clamp 0; j = -0.001 as i32 = 0
+    assert color(0.26, float("nan")) == list(tex[0, 1])         # NaN as i32 = 0
+    L.ora_texture_color(tex.ctypes.data, 4, 2, 0.5, 0.5, col)
+    assert col[0] == float(F(tex[0, 2, 0]) / F(255.0))          # true division by 255 (picture.rs:33)
+
+
+def test_portable_rsqrt(oracle):
+    L = oracle.load()
+    assert L.ora_rsqrt(4.0) == 0.5 and L.ora_rsqrt(0.25) == 2.0
+    assert L.ora_rsqrt(0.0) == float("inf")                     # normalising (0,0,0) gives 0 * inf = NaN
+    x = F(3.0)
+    assert L.ora_rsqrt(3.0) == float(F(1.0) / np.sqrt(x))
+
+
+def test_portable_atan2_asin_against_libm(oracle):
+    """P2: fp64-evaluated, rounded once.  Must equal the correctly rounded value (fp64 libm result
+    rounded to fp32) except where fp64 libm itself is within rounding of an fp32 midpoint."""
+    L = oracle.load()
+    rng = np.random.default_rng(1)
+    ys = rng.uniform(-1, 1, 20000).astype(F)
+    xs = rng.uniform(-1, 1, 20000).astype(F)
+    bad = 0
+    for y, x in zip(ys, xs):
+        want = F(math.atan2(float(y), float(x)))
+        got = F(L.ora_atan2f(float(y), float(x)))
+        if got != want:
+            bad += 1
+            assert abs(int(got.view(np.int32)) - int(want.view(np.int32))) <= 1
+        want = F(math.asin(float(y)))
+        got = F(L.ora_asinf(float(y)))
+        if got != want:
+            bad += 1
+            assert abs(int(got.view(np.int32)) - int(want.view(np.int32))) <= 1
+    assert bad <= 2
+    assert L.ora_atan2f(0.0, 1.0) == 0.0 and L.ora_atan2f(0.0, -1.0) == float(F(math.pi))
+    assert L.ora_atan2f(1.0, 0.0) == float(F(math.pi / 2)) and L.ora_atan2f(-1.0, 0.0) == float(F(-math.pi / 2))
+    assert L.ora_asinf(1.0) == float(F(math.pi / 2)) and L.ora_asinf(-1.0) == float(F(-math.pi / 2))
+    assert math.isnan(L.ora_asinf(1.0000001))
+
+
+def test_camera_corner_rays(oracle):
+    # camera.rs:14-44: eye 0, looking down -z, fov 90, 2:1 -> half_height = tan(45 deg), half_width = 2 tan(45 deg)
+    L = oracle.load()
+    cam = oracle.OraCamera()
+    L.ora_camera_new(f3((0, 0, 0)), f3((0, 0, -1)), f3((0, 1, 0)), 90.0, 200, 100, C.byref(cam))
+    hh = math.tan(math.radians(90.0) / 2)
+    assert np.allclose(cam.llc[:], [-2 * hh, -hh, -1.0], atol=1e-6)
+    assert np.allclose(cam.horizontal[:], [4 * hh, 0, 0], atol=1e-6)
+    assert np.allclose(cam.vertical[:], [0, 2 * hh, 0], atol=1e-6)
+    assert cam.origin[:] == [0.0, 0.0, 0.0] and (cam.width, cam.height) == (200, 100)
+
+
+def test_trace_ray_sky_only(oracle):
+    """A ray that misses everything returns the sky gradient (raytracer.rs:67-70) -- hand computed."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0, 0, 100), 0.5, pt.Lambertian.new_solid((0.5, 0.5, 0.5))))   # behind the camera
+    cam = pt.Camera.new((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, 4, 2)
+    rt = pt.Raytracer.new(cam, scene, 2)
+    osc = oracle.OracleScene(rt.packed)
+    got = osc.trace_path(cam.pod, 2, 0, 1, 0, 0)
+    # the camera ray is NOT normalised (camera.rs:41-43): t uses the raw direction's y
+    d = np.array(cam.pod.lower_left_corner[:], F) + np.array(cam.pod.horizontal[:], F) * F(F(1.0) / F(4.0)) \
+        + np.array(cam.pod.vertical[:], F) * F(F(1.0) - F(0.0) / F(2.0)) - np.array(cam.pod.origin[:], F)
+    t = F(0.5) * (d[1] + F(1.0))
+    want = np.array([1, 1, 1], F) * (F(1.0) - t) + np.array([0.5, 0.7, 1.0], F) * t
+    assert np.array_equal(got, want.astype(F))
+
+
+def test_resolve_truncates_and_saturates(oracle):
+    # raytracer.rs:92-93,119-121: sqrt(sum / S^2) * 255 `as u8` (truncate, saturate, NaN -> 0)
+    L = oracle.load()
+    rad = np.array([[4.0, 1.0, 0.0], [16.0, np.nan, -1.0], [0.9999 * 4, 2.0, 1e-9]], F)
+    out = np.zeros((3, 3), np.uint8)
+    L.ora_resolve(rad.ctypes.data, 3, 2, out.ctypes.data)
+    assert list(out[0]) == [255, 127, 0]        # sqrt(1)=1 -> 255; sqrt(.25)*255 = 127.5 -> 127
+    assert list(out[1]) == [255, 0, 0]          # 2.0*255 saturates; NaN -> 0; sqrt(-0.25) = NaN -> 0
+    assert out[2, 0] == 254                     # just under 1.0 truncates to 254
