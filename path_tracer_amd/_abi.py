@@ -86,6 +86,13 @@ def lib():
             raise RuntimeError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        try:
+            # One HIP runtime per process: when PyTorch is installed, let it load its own
+            # libamdhip64 first so that torch tensors / streams and this library share it
+            # (loading /opt/rocm's copy first leaves torch with "No HIP GPUs are available").
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if a declared symbol is not exported

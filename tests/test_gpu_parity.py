@@ -131,3 +131,156 @@ def test_error_codes(renderer):
     with pytest.raises(ValueError):
         renderer.render(rt, buffer=np.zeros((3, 3, 3), np.uint8))
     assert renderer.render(rt).shape == (16, 32, 3)        # the context survives the errors
+
+
+def test_axis_aligned_rays_nan_and_inf_slabs(renderer, oracle):
+    """Camera looking straight down -z with eye.x = eye.y = 0: the centre column / row of
+    pixels get direction components that are EXACTLY zero (1/0 = inf), and spheres are placed
+    so that box planes coincide with the ray origin (0 * inf = NaN).  These rays take the
+    general slab path (SSE 'second operand on NaN' rule, aabb.rs:25-36 + vec.rs:50-51)."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    grey = pt.Lambertian.new_solid((0.6, 0.6, 0.6))
+    metal = pt.Metal.new((0.9, 0.9, 0.9), 0.0)
+    glass = pt.Dielectric.new(1.5)
+    # bmin.x = 0 / bmax.x = 0 / bmin.y = 0 / bmax.y = 0 planes through the camera axis
+    scene.add(pt.Sphere.new((0.5, 0.0, -3.0), 0.5, grey))
+    scene.add(pt.Sphere.new((-0.5, 0.0, -4.0), 0.5, metal))
+    scene.add(pt.Sphere.new((0.0, 0.5, -5.0), 0.5, glass))
+    scene.add(pt.Sphere.new((0.0, -0.5, -6.0), 0.5, grey))
+    scene.add(pt.Sphere.new((0.0, 0.0, -9.0), 1.0, metal))
+    scene.add(pt.Sphere.new((0.0, -101.0, -5.0), 100.0, grey))
+    w, h, s = 32, 16, 3
+    cam = pt.Camera.new((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 40.0, w, h)
+    rt = pt.Raytracer.new(cam, scene, s)
+    pod = cam.pod
+    # sample 0 of column w/2 has u = 0.5 exactly -> dir.x == 0; row h/2 has v = 0.5 -> dir.y == 0
+    dx = (np.float32(pod.lower_left_corner[0]) + np.float32(pod.horizontal[0]) * np.float32(0.5)) - np.float32(pod.origin[0])
+    dy = (np.float32(pod.lower_left_corner[1]) + np.float32(pod.vertical[1]) * np.float32(0.5)) - np.float32(pod.origin[1])
+    assert dx == 0.0 and dy == 0.0
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(pod, s, seed=11, hit_ids=True)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        img, rad, ids = renderer.render(rt, seed=11, radiance=True, hit_ids=True)
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert np.array_equal(ids, ref["hit_id"])
+    assert same_bits(rad, ref["radiance"])
+    assert np.array_equal(img, osc.resolve(ref["radiance"], s))
+
+
+def test_textured_sphere_poles_and_seam(renderer, oracle):
+    """Earth sphere seen from above its pole and along the u seam: exercises atan2(0,0),
+    |n.y| >= 1 -> NaN -> row 0, and the clamp of picture.rs:24-26."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, 0.0, 0.0), 1.0, pt.Lambertian.new(pt.PictureTexture.earthmap())))
+    for eye in ((0.0, 4.0, 0.0001), (-4.0, 0.0, 0.0), (0.0, -4.0, 0.0001)):
+        cam = pt.Camera.new(eye, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0) if eye[1] else (0.0, 1.0, 0.0), 35.0, 48, 48)
+        rt = pt.Raytracer.new(cam, scene, 2)
+        osc = oracle.OracleScene(rt.packed)
+        ref = osc.render(cam.pod, 2, seed=3)["radiance"]
+        renderer.set_lanes_per_pixel(1)
+        try:
+            _, rad, _ = renderer.render(rt, seed=3, radiance=True)
+        finally:
+            renderer.set_lanes_per_pixel(0)
+        assert same_bits(rad, ref)
+
+
+def test_single_sphere_scene_root_is_a_leaf(renderer, oracle):
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, 0.0, -2.0), 0.7, pt.Dielectric.new(1.5)))
+    cam = pt.Camera.new((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 50.0, 40, 24)
+    rt = pt.Raytracer.new(cam, scene, 3)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(cam.pod, 3, seed=2, hit_ids=True)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        _, rad, ids = renderer.render(rt, seed=2, radiance=True, hit_ids=True)
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert np.array_equal(ids, ref["hit_id"]) and same_bits(rad, ref["radiance"])
+
+
+def test_library_built_bvh_equals_host_built(renderer):
+    """nodes = NULL: pt_upload_scene builds the tree itself (bvh.rs:13-91)."""
+    import path_tracer_amd as pt
+    rt = make_raytracer("rtow", 80, 45, 2)
+    a = renderer.render(rt, seed=1, radiance=True)[1]
+    rt2 = make_raytracer("rtow", 80, 45, 2)
+    rt2.nodes = None
+    b = renderer.render(rt2, seed=1, radiance=True)[1]
+    assert same_bits(a, b)
+
+
+def test_big_scene_beyond_lds_prefix(renderer, oracle):
+    """~10.7k spheres: only the top 1024 nodes sit in LDS, the rest come through the L1."""
+    rt = make_raytracer("reference", 120, 68, 2)
+    assert len(rt.nodes) > 1024
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, 2, seed=RENDER_SEED, hit_ids=True)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        _, rad, ids = renderer.render(rt, seed=RENDER_SEED, radiance=True, hit_ids=True)
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert np.array_equal(ids, ref["hit_id"]) and same_bits(rad, ref["radiance"])
+
+
+def test_accumulate_continues_the_sequential_sum(renderer, oracle):
+    """pt_render_device(accumulate=1) continues the per-pixel sum where the previous launch
+    stopped: two launches over [0,k) and [k,S^2) equal one launch, bit for bit."""
+    import torch
+    rt = make_raytracer("rtow", 72, 40, 3)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, 3, seed=9)["radiance"]
+    acc = torch.zeros(72 * 40 * 3, dtype=torch.float32, device="cuda")
+    renderer.set_lanes_per_pixel(1)
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        renderer.render_device(rt, acc.data_ptr(), seed=9, sample_range=(0, 4), stream=st)
+        renderer.render_device(rt, acc.data_ptr(), seed=9, sample_range=(4, 9), accumulate=True, stream=st)
+        torch.cuda.synchronize()
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert same_bits(acc.cpu().numpy().reshape(40, 72, 3), ref)
+
+
+def test_full_size_properties_1080p(renderer, oracle):
+    """BASELINE frame size (1920x1080, the earth scene) at reduced spp -- properties that need no
+    full-size oracle run: (1) determinism, (2) primary hit ids = the oracle's (cheap: no paths),
+    (3) sample shards sum to the frame, (4) oracle agreement on a 64-row band."""
+    import path_tracer_amd as pt
+    rt = make_raytracer("simple", 1920, 1080, 4)
+    a = renderer.render(rt, seed=5, radiance=True, hit_ids=True)
+    b = renderer.render(rt, seed=5, radiance=True)
+    assert same_bits(a[1], b[1]) and np.array_equal(a[0], b[0])
+    osc = oracle.OracleScene(rt.packed)
+    assert np.array_equal(a[2], osc.render(rt.camera.pod, 4, radiance=False, hit_ids=True)["hit_id"])
+    parts = sum(renderer.render(rt, seed=5, sample_range=pt.shard_range(4, r, 2), radiance=True)[1] for r in range(2))
+    assert np.allclose(parts, a[1], rtol=2e-6, atol=1e-6)
+    other = renderer.render(rt, seed=6, radiance=True)[1]
+    assert not same_bits(other, a[1])                       # the seed matters
+    assert np.isfinite(a[1]).all() and (a[1] >= 0).all()
+
+
+def test_cfg1_frame_against_oracle(renderer, oracle):
+    """BASELINE config 1 at its real size: RTOW scene 400x225 @ 100 spp (9 M paths; the oracle
+    needs a few seconds).  Auto lanes-per-pixel (8): bit-exact against the oracle's chunked sum,
+    >= 99.9 % of pixels within 1/255 of the sequential-order frame, RMSE far below 1e-3."""
+    rt = make_raytracer("rtow", 400, 225, 10)
+    osc = oracle.OracleScene(rt.packed)
+    renderer.bind(rt)
+    lanes = renderer.lanes_per_pixel(10, 0, 100)
+    img, rad, ids = renderer.render(rt, seed=RENDER_SEED, radiance=True, hit_ids=True)
+    chunk = -(-100 // lanes)
+    ref_chunked = osc.render(rt.camera.pod, 10, seed=RENDER_SEED, chunk=chunk, hit_ids=True)
+    assert np.array_equal(ids, ref_chunked["hit_id"])
+    assert same_bits(rad, ref_chunked["radiance"])
+    seq = osc.render(rt.camera.pod, 10, seed=RENDER_SEED)["radiance"]
+    assert tonemapped_agreement(osc, rad, seq, 10) >= 0.999
+    tm = lambda r: np.sqrt(r / np.float32(100.0))
+    assert float(np.sqrt(np.mean((tm(rad) - tm(seq)) ** 2))) < 1e-3
