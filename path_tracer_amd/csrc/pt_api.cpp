@@ -53,6 +53,9 @@ struct pt_context {
     int64_t frame_pixels = 0;
 
     int32_t lanes_override = 0;
+
+    int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
+    size_t sched_bytes = 0;
 };
 
 namespace {
@@ -177,6 +180,7 @@ void pt_destroy(pt_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_frame(c);
+    if (c->d_sched) (void)hipFree(c->d_sched);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -364,6 +368,16 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
     c->camera.width = cam->width;
     c->camera.height = cam->height;
     c->have_camera = true;
+    const size_t need = ptk::sched_bytes(c->camera);
+    if (need > c->sched_bytes) {
+        PT_HIP(c, hipSetDevice(c->device));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_sched) (void)hipFree(c->d_sched);
+        c->d_sched = nullptr;
+        c->sched_bytes = 0;
+        PT_HIP(c, hipMalloc((void **)&c->d_sched, need));
+        c->sched_bytes = need;
+    }
     return PT_OK;
 }
 
@@ -407,7 +421,7 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     rp.stats = d_stats;
 #endif
     PT_HIP(c, hipEventRecord(c->ev_start, st));
-    PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, d_radiance, st));
+    PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, c->d_sched, d_radiance, st));
     PT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->timed = true;
 #ifdef PT_STATS
@@ -473,6 +487,12 @@ int pt_render(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begi
         PT_HIP(c, hipMemcpyAsync(hit_id, c->d_hit_id, px * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     }
     PT_HIP(c, hipStreamSynchronize(c->stream));
+    if (rgb8 || radiance) {
+        // the kernel's bounded dependency wait (pt_kernels.hip) reports here instead of hanging
+        int32_t ctrl[2] = {0, 0};
+        PT_HIP(c, hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost));
+        if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
+    }
     return PT_OK;
 }
 

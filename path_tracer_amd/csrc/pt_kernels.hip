@@ -74,8 +74,8 @@ constexpr int WAVES_PER_GROUP = 4;
 #endif
 
 template <bool ALL_IN_LDS>
-__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, int n_tiles,
-                                                                    float *__restrict__ radiance)
+__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
+                                                                    float *radiance)
 {
     extern __shared__ float4 lds_n0[];
     const int lds_nodes = sc.lds_nodes;
@@ -83,30 +83,54 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * WAVES_PER_GROUP + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
     const int L = rp.lanes;
     const int P = 64 / L;
     int tw, th;
     tile_shape(L, tw, th);
     const int slot = lane % P, chunk = lane / P;
     const int tiles_x = (cam.width + tw - 1) / tw;
+    const int S = rp.S;
+    const int n_nodes = sc.n_nodes;
+    const int n_items = sched.n_tiles * sched.n_pieces;
+    const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, n_nodes * 16, 0x00020000);
+
+  // Persistent wave: draw (piece, tile) items until none are left.  Fine-grained items keep
+  // every SIMD's wave slots full until the very end of the frame (a whole tile x all samples
+  // per wave left the chip at 4.75 of 8 waves per SIMD on average: profiles/r01/v2).
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(&sched.ctrl[0], 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= n_items) break;
+    const int piece = item / sched.n_tiles, tile = item - piece * sched.n_tiles;
+    const int ps0 = rp.s0 + piece * sched.piece_len;
+    const int ps1 = ps0 + sched.piece_len < rp.s1 ? ps0 + sched.piece_len : rp.s1;
     const int px = (tile % tiles_x) * tw + slot % tw;
     const int py = (tile / tiles_x) * th + slot / tw;
     const bool valid = px < cam.width && py < cam.height;
     const uint32_t pixel = (uint32_t)(py * cam.width + px);
 
-    const int per = (rp.s1 - rp.s0 + L - 1) / L;
-    int s = rp.s0 + chunk * per;
-    int s_end = s + per < rp.s1 ? s + per : rp.s1;
+    const int per = (ps1 - ps0 + L - 1) / L;
+    int s = ps0 + chunk * per;
+    int s_end = s + per < ps1 ? s + per : ps1;
     if (!valid) s_end = s;
+    const bool resume = rp.accumulate || piece > 0;
+
+    if (piece > 0) {
+        // the previous piece of this tile was drawn earlier, by a wave that is running: wait for
+        // its sums (agent-scope acquire: cdna_hip_programming.md guideline 16); bounded spin
+        int spins = 0;
+        while (__hip_atomic_load(&sched.done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1 << 22)) { sched.ctrl[1] = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     f3 sum = fill(0.0f);
-    if (L == 1 && rp.accumulate && valid)
+    if (L == 1 && resume && valid)
         sum = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
-
-    const int S = rp.S;
-    const int n_nodes = sc.n_nodes;
 
     // Per-lane state.  `code` is the whole control state of the lane: a node code while
     // the walk stands on a node (Split: [0, n_nodes), Leaf: sign bit set), n_nodes when
@@ -122,7 +146,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     uint64_t rng = 0;
     bool regular = true, to_sky = true;
 
-    const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, n_nodes * 16, 0x00020000);
     // n1[i] through the L1 (one 32-bit byte offset serves both arrays), n0[i] from LDS when staged
     auto fetch = [&](int32_t c, float4 &n0, float4 &n1) {
         const int off = code_index(c) << 4;
@@ -234,19 +257,27 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
 #endif
     if (L == 1) {
         if (valid) { radiance[3 * pixel] = sum.x; radiance[3 * pixel + 1] = sum.y; radiance[3 * pixel + 2] = sum.z; }
-        return;
+    } else {
+        // lanes_per_pixel > 1: the pixel's chunk sums, added in chunk order by its chunk-0 lane
+        f3 total = fill(0.0f);
+        if (resume && chunk == 0 && valid)
+            total = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
+        for (int k = 0; k < L; k++) {
+            const int src = k * P + slot;
+            total = total + mk(__shfl(sum.x, src), __shfl(sum.y, src), __shfl(sum.z, src));
+        }
+        if (chunk == 0 && valid) {
+            radiance[3 * pixel] = total.x; radiance[3 * pixel + 1] = total.y; radiance[3 * pixel + 2] = total.z;
+        }
     }
-    // lanes_per_pixel > 1: the pixel's chunk sums, added in chunk order by its chunk-0 lane
-    f3 total = fill(0.0f);
-    if (rp.accumulate && chunk == 0 && valid)
-        total = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
-    for (int k = 0; k < L; k++) {
-        const int src = k * P + slot;
-        total = total + mk(__shfl(sum.x, src), __shfl(sum.y, src), __shfl(sum.z, src));
+    if (sched.n_pieces > 1) {
+        // publish this piece's sums for the wave that draws the tile's next piece
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&sched.done[tile], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (chunk == 0 && valid) {
-        radiance[3 * pixel] = total.x; radiance[3 * pixel + 1] = total.y; radiance[3 * pixel + 2] = total.z;
-    }
+  }
 }
 
 // K1: primitive id (and t) hit by the primary ray of one sample index.
@@ -297,17 +328,41 @@ int tiles_for(const Camera &cam, int lanes)
     return ((cam.width + tw - 1) / tw) * ((cam.height + th - 1) / th);
 }
 
-hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &rp, float *d_radiance, hipStream_t stream)
+// control words + one `done` word per 8x8 tile (the only tiling that is split into pieces)
+size_t sched_bytes(const Camera &cam) { return (64 + (size_t)tiles_for(cam, 1)) * sizeof(int32_t); }
+
+hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &rp, int32_t *d_sched, float *d_radiance,
+                       hipStream_t stream)
 {
-    const int tiles = tiles_for(cam, rp.lanes);
-    const int groups = (tiles + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
+    SchedParams sp;
+    sp.n_tiles = tiles_for(cam, rp.lanes);
+    sp.ctrl = d_sched;
+    sp.done = d_sched + 64;
+    // enough items that the last ones are a small fraction of a wave slot's share of the frame
+    // (256 CUs x 32 wave slots x 64 items); whole-pixel lanes only, at least 8 samples per piece
+    const int count = rp.s1 - rp.s0;
+    int pieces = 1;
+    if (rp.lanes == 1 && count > 8) {
+        const long long want = 256ll * 32 * 64;
+        pieces = (int)((want + sp.n_tiles - 1) / sp.n_tiles);
+        if (pieces > count / 8) pieces = count / 8;
+        if (pieces < 1) pieces = 1;
+    }
+    sp.piece_len = (count + pieces - 1) / pieces;
+    sp.n_pieces = sp.piece_len > 0 ? (count + sp.piece_len - 1) / sp.piece_len : 1;
+    if (sp.n_pieces < 1) sp.n_pieces = 1;
+    hipError_t e = hipMemsetAsync(d_sched, 0, sched_bytes(cam), stream);
+    if (e != hipSuccess) return e;
+    const long long items = (long long)sp.n_tiles * sp.n_pieces;
+    long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
+    if (groups > 256 * 8) groups = 256 * 8;     // 8 workgroups x 4 waves fill a CU's 32 wave slots
     const size_t lds_bytes = (size_t)sc.lds_nodes * sizeof(float4);
     if (sc.lds_nodes >= sc.n_nodes)
-        hipLaunchKernelGGL(path_kernel<true>, dim3(groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam, rp,
-                           tiles, d_radiance);
+        hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
+                           rp, sp, d_radiance);
     else
-        hipLaunchKernelGGL(path_kernel<false>, dim3(groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam, rp,
-                           tiles, d_radiance);
+        hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
+                           rp, sp, d_radiance);
     return hipGetLastError();
 }
 

@@ -11,10 +11,21 @@ struct RenderParams {
     unsigned long long *stats;   // PT_STATS builds only: 8 counters {steps, active lanes} x {SPLIT, LEAF, HIT, END}
 };
 
+// Work distribution of the path kernel: persistent waves draw (piece, tile) items from
+// one counter, piece-major.  A piece is a contiguous run of `piece_len` sample indices;
+// piece k of a tile continues the per-pixel sums piece k-1 left in the radiance buffer
+// (same sequential fp32 order as one long run) and therefore waits for done[tile] >= k.
+struct SchedParams {
+    int32_t n_tiles, n_pieces, piece_len;
+    int32_t *ctrl;        // [0] next item, [1] error flag (a dependency wait gave up)
+    int32_t *done;        // per tile: pieces completed
+};
+
 namespace ptk {
 int tiles_for(const ptd::Camera &cam, int lanes);
-hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, float *d_radiance,
-                       hipStream_t stream);
+hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
+                       float *d_radiance, hipStream_t stream);
+size_t sched_bytes(const ptd::Camera &cam);
 hipError_t launch_primary_hits(const ptd::Scene &sc, const ptd::Camera &cam, int S, int sample, int32_t *d_hit_id,
                                float *d_hit_t, hipStream_t stream);
 hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t *d_rgb8, hipStream_t stream);
