@@ -416,8 +416,8 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     rp.stats = nullptr;
 #ifdef PT_STATS
     static unsigned long long *d_stats = nullptr;
-    if (!d_stats) (void)hipMalloc((void **)&d_stats, 64);
-    (void)hipMemsetAsync(d_stats, 0, 64, st);
+    if (!d_stats) (void)hipMalloc((void **)&d_stats, 128);
+    (void)hipMemsetAsync(d_stats, 0, 128, st);
     rp.stats = d_stats;
 #endif
     PT_HIP(c, hipEventRecord(c->ev_start, st));
@@ -426,12 +426,17 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     c->timed = true;
 #ifdef PT_STATS
     {
-        unsigned long long hs[8];
-        (void)hipMemcpyAsync(hs, d_stats, 64, hipMemcpyDeviceToHost, st);
+        unsigned long long hs[16];
+        (void)hipMemcpyAsync(hs, d_stats, 128, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         const char *nm[4] = {"SPLIT", "LEAF", "HIT", "END"};
         for (int k = 0; k < 4; k++)
             fprintf(stderr, "[pt stats] %-5s steps %llu  lanes/step %.1f\n", nm[k], hs[2 * k], hs[2 * k] ? (double)hs[2 * k + 1] / hs[2 * k] : 0.0);
+        const char *tn[6] = {"SPLIT", "LEAF", "HIT", "END", "vote", "tails"};
+        double tot = 0;
+        for (int k = 0; k < 6; k++) tot += (double)hs[8 + k];
+        for (int k = 0; k < 6; k++)
+            fprintf(stderr, "[pt stats] wave cycles in %-5s %5.1f %%  (%.0f cycles per step)\n", tn[k], 100.0 * hs[8 + k] / tot, k < 4 && hs[2 * k] ? (double)hs[8 + k] / hs[2 * k] : 0.0);
     }
 #endif
     return PT_OK;

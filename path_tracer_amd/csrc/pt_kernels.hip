@@ -45,14 +45,14 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 // ends, and box tests / sphere tests / shading are not serialised against each
 // other inside one iteration.  Each lane still executes exactly the reference's
 // operation sequence for its pixel, so results do not depend on the vote.
-#ifndef PT_SPLIT_DROP
-#define PT_SPLIT_DROP 2   // a SPLIT run ends once a quarter of its lanes have left the state
+#ifndef PT_SPLIT_KEEP
+#define PT_SPLIT_KEEP 4   // a SPLIT run goes on while at least KEEP/8 of the lanes it started with are still at a Split
 #endif
 #ifndef PT_W_SPLIT
 #define PT_W_SPLIT 1
 #endif
 #ifndef PT_W_LEAF
-#define PT_W_LEAF 1
+#define PT_W_LEAF 2
 #endif
 #ifndef PT_W_HIT
 #define PT_W_HIT 1
@@ -68,7 +68,10 @@ enum : int { ST_SPLIT = 0, ST_LEAF = 1, ST_HIT = 2, ST_END = 3, ST_DONE = 4 };
 // through the vector L1, so a node visit puts one 16-byte access on each of the two
 // memory pipes of the CU instead of two on the L1 (the measured bottleneck:
 // profiles/r01).
-constexpr int WAVES_PER_GROUP = 4;
+#ifndef PT_WAVES_PER_GROUP
+#define PT_WAVES_PER_GROUP 4
+#endif
+constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 8   // waves per SIMD the register allocator must leave room for (64 VGPRs)
 #endif
@@ -162,9 +165,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     // new_walk -> Scene::trace prologue (scene/mod.rs:24-34), standing on the root.
 #ifdef PT_STATS
     unsigned st_n[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};
+    unsigned long long st_c[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
 #define PT_STAT(k, n) do { st_n[k] += 1; st_l[k] += (n); } while (0)
+#define PT_TIME(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_c[k] += t_ - st_t; st_t = t_; } while (0)
 #else
 #define PT_STAT(k, n) do { } while (0)
+#define PT_TIME(k) do { } while (0)
 #endif
     bool new_path = true, new_walk = false;
     for (;;) {
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             code = sc.root_code;
         }
         new_path = false; new_walk = false;
+        PT_TIME(5);
 
         int pick;
         for (;;) {
@@ -198,9 +205,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             v = cH * PT_W_HIT;  if (v > top) { top = v; pick = ST_HIT; }
             v = cE * PT_W_END;  if (v > top) { top = v; pick = ST_END; }
             if (top == 0) pick = ST_DONE;
+            PT_TIME(4);
             if (pick == ST_SPLIT) {
                 const bool all_regular = __ballot((uint32_t)code < (uint32_t)n_nodes && !regular) == 0ull;
-                const int keep = cS - (cS >> PT_SPLIT_DROP);   // leave when this many lanes have left SPLIT
+                const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
                 bool at_split = (uint32_t)code < (uint32_t)n_nodes;
                 do {
                     PT_STAT(0, lanes(at_split));
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                     }
                     at_split = (uint32_t)code < (uint32_t)n_nodes;
                 } while (lanes(at_split) >= keep && keep > 0);
+                PT_TIME(0);
             } else if (pick == ST_LEAF) {
                 PT_STAT(1, cL);
                 if (code < 0) {
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                     leaf_step(n0, n1, ray.o, ray.d, a, h);
                     code = __float_as_int(n1.w);
                 }
+                PT_TIME(1);
             } else break;
         }
         if (pick == ST_DONE) break;
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                     code = C_END; to_sky = false;                                // raytracer.rs:60: return 0
                 }
             }
+            PT_TIME(2);
         } else {
             PT_STAT(3, lanes(code == C_END));
             if (code == C_END) {
@@ -248,12 +259,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 s++;
                 new_path = true;
             }
+            PT_TIME(3);
         }
     }
 
 #ifdef PT_STATS
     if (lane == 0 && rp.stats)
         for (int k = 0; k < 4; k++) { atomicAdd(&rp.stats[2 * k], (unsigned long long)st_n[k]); atomicAdd(&rp.stats[2 * k + 1], (unsigned long long)st_l[k]); }
+    if (lane == 0 && rp.stats)
+        for (int k = 0; k < 6; k++) atomicAdd(&rp.stats[8 + k], st_c[k]);
 #endif
     if (L == 1) {
         if (valid) { radiance[3 * pixel] = sum.x; radiance[3 * pixel + 1] = sum.y; radiance[3 * pixel + 2] = sum.z; }
@@ -357,6 +371,7 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
     if (groups > 256 * 8) groups = 256 * 8;     // 8 workgroups x 4 waves fill a CU's 32 wave slots
     const size_t lds_bytes = (size_t)sc.lds_nodes * sizeof(float4);
+    if (groups > 256 * 32 / WAVES_PER_GROUP) groups = 256 * 32 / WAVES_PER_GROUP;
     if (sc.lds_nodes >= sc.n_nodes)
         hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
                            rp, sp, d_radiance);
