@@ -478,12 +478,20 @@ static void bvh_free(bvh_node *n)
     if (!n) return;
     bvh_free(n->left); bvh_free(n->right); free(n);
 }
+/* optional per-thread event log (tools/sim_vote.py): 'S' box test, 'L' sphere test that misses, 'X' one that hits,
+ * 'H' scatter, 'E' end of path */
+static __thread char *ev_buf; static __thread int ev_n, ev_cap;
+static inline void ev(char c) { if (ev_buf) { if (ev_n < ev_cap) ev_buf[ev_n] = c; ev_n++; } }
 /* bvh.rs:106-127 */
 static int bvh_trace(const ora_scene *sc, const bvh_node *n, const ray_t *ray, v3 inv, float min_t,
                      float max_t, hit_t *h, ora_counters *cnt)
 {
-    if (n->is_leaf)
-        return sphere_trace(&sc->spheres[n->prim], n->prim, ray, min_t, max_t, h, cnt);
+    if (n->is_leaf) {
+        int r = sphere_trace(&sc->spheres[n->prim], n->prim, ray, min_t, max_t, h, cnt);
+        ev(r ? 'X' : 'L');
+        return r;
+    }
+    ev('S');
     if (cnt) cnt->aabb_tests++;
     if (!aabb_intersect(n->bmin, n->bmax, ray, inv, min_t, max_t)) return 0;
     hit_t hl;
@@ -612,16 +620,19 @@ static v3 trace_ray(const ora_scene *sc, ray_t ray, rng_t *rng, ora_counters *cn
         if (cnt) cnt->segments++;
         if (scene_trace(sc, &ray, &h, cnt)) {
             v3 att; ray_t nr;
+            ev('H');
             if (scatter(sc, &ray, &h, rng, &att, &nr, cnt)) {
                 attenuation = vmul(attenuation, att);
                 ray = nr;
             } else {
+                ev('E');
                 return vfill(0.0f);
             }
         } else {
             break;
         }
     }
+    ev('E');
     if (cnt) cnt->sky_evals++;
     float t = 0.5f * (ray.d.y + 1.0f);
     v3 color = vadd(vmulf(V(1.0f, 1.0f, 1.0f), 1.0f - t), vmulf(V(0.5f, 0.7f, 1.0f), t));
@@ -831,6 +842,17 @@ ORA_API void ora_trace_path(const ora_scene *sc, const ora_camera *cam, int32_t 
     rng_t rng = {ora_rng_with_seed(ora_path_seed(seed, pixel, (uint32_t)s)), NULL};
     v3 c = trace_ray(sc, sample_ray(cam, samples, px, py, s), &rng, NULL);
     out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
+}
+
+/* the same path, returning its event string (see ev()); result = events produced */
+ORA_API int32_t ora_trace_path_events(const ora_scene *sc, const ora_camera *cam, int32_t samples, uint64_t seed,
+                                      int32_t px, int32_t py, int32_t s, char *buf, int32_t cap)
+{
+    float rgb[3];
+    ev_buf = buf; ev_n = 0; ev_cap = cap;
+    ora_trace_path(sc, cam, samples, seed, px, py, s, rgb);
+    ev_buf = NULL;
+    return ev_n;
 }
 
 /* ------------------------------------------------------- scene generators */

@@ -48,6 +48,12 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #ifndef PT_SPLIT_KEEP
 #define PT_SPLIT_KEEP 4   // a SPLIT run goes on while at least KEEP/8 of the lanes it started with are still at a Split
 #endif
+#ifndef PT_PIECE_MIN
+#define PT_PIECE_MIN 8        // fewest sample indices in a piece
+#endif
+#ifndef PT_ITEMS_PER_SLOT
+#define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
+#endif
 #ifndef PT_W_SPLIT
 #define PT_W_SPLIT 1
 #endif
@@ -356,10 +362,10 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     // (256 CUs x 32 wave slots x 64 items); whole-pixel lanes only, at least 8 samples per piece
     const int count = rp.s1 - rp.s0;
     int pieces = 1;
-    if (rp.lanes == 1 && count > 8) {
-        const long long want = 256ll * 32 * 64;
+    if (rp.lanes == 1 && count > PT_PIECE_MIN) {
+        const long long want = 256ll * 32 * PT_ITEMS_PER_SLOT;
         pieces = (int)((want + sp.n_tiles - 1) / sp.n_tiles);
-        if (pieces > count / 8) pieces = count / 8;
+        if (pieces > count / PT_PIECE_MIN) pieces = count / PT_PIECE_MIN;
         if (pieces < 1) pieces = 1;
     }
     sp.piece_len = (count + pieces - 1) / pieces;
