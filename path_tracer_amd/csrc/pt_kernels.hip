@@ -49,7 +49,7 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #define PT_SPLIT_KEEP 4   // a SPLIT run goes on while at least KEEP/8 of the lanes it started with are still at a Split
 #endif
 #ifndef PT_PIECE_MIN
-#define PT_PIECE_MIN 8        // fewest sample indices in a piece
+#define PT_PIECE_MIN 32       // fewest sample indices in a piece (each piece ends with a drain of the wave)
 #endif
 #ifndef PT_ITEMS_PER_SLOT
 #define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
@@ -87,6 +87,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                                                                     float *radiance)
 {
     extern __shared__ float4 lds_n0[];
+    __shared__ int ticket;
+    // One ticket per workgroup, drawn while the nodes are staged: the group's waves take the
+    // (piece, tile) items 4*ticket .. 4*ticket+3.  Tickets follow the order in which groups
+    // START, so the item a wave may have to wait for (same tile, previous piece: a lower
+    // item) belongs to a group that is already running or done -- whatever order the
+    // hardware dispatches blockIdx in.
+    if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
     const int lds_nodes = sc.lds_nodes;
     for (int i = threadIdx.x; i < lds_nodes; i += 64 * WAVES_PER_GROUP) lds_n0[i] = sc.n0[i];
     __syncthreads();
@@ -103,14 +110,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     const int n_items = sched.n_tiles * sched.n_pieces;
     const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, n_nodes * 16, 0x00020000);
 
-  // Persistent wave: draw (piece, tile) items until none are left.  Fine-grained items keep
-  // every SIMD's wave slots full until the very end of the frame (a whole tile x all samples
-  // per wave left the chip at 4.75 of 8 waves per SIMD on average: profiles/r01/v2).
-  for (;;) {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(&sched.ctrl[0], 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= n_items) break;
+  // A wave renders ONE item: a tile's pixels x a contiguous piece of the sample indices.
+  // Fine-grained items keep every SIMD's wave slots full until the very end of the frame (a
+  // whole tile x all samples per wave left the chip at 4.75 of 8 waves per SIMD on average:
+  // profiles/r01/v2); a loop over items inside the wave cost 4-20 % in code quality.
+  {
+    const int item = __builtin_amdgcn_readfirstlane(ticket) * WAVES_PER_GROUP + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (item >= n_items) return;
     const int piece = item / sched.n_tiles, tile = item - piece * sched.n_tiles;
     const int ps0 = rp.s0 + piece * sched.piece_len;
     const int ps1 = ps0 + sched.piece_len < rp.s1 ? ps0 + sched.piece_len : rp.s1;
@@ -359,7 +365,7 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     sp.ctrl = d_sched;
     sp.done = d_sched + 64;
     // enough items that the last ones are a small fraction of a wave slot's share of the frame
-    // (256 CUs x 32 wave slots x 64 items); whole-pixel lanes only, at least 8 samples per piece
+    // (256 CUs x 32 wave slots x 64 items); whole-pixel lanes only, at least PT_PIECE_MIN samples per piece
     const int count = rp.s1 - rp.s0;
     int pieces = 1;
     if (rp.lanes == 1 && count > PT_PIECE_MIN) {
@@ -375,9 +381,7 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     if (e != hipSuccess) return e;
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
-    if (groups > 256 * 8) groups = 256 * 8;     // 8 workgroups x 4 waves fill a CU's 32 wave slots
     const size_t lds_bytes = (size_t)sc.lds_nodes * sizeof(float4);
-    if (groups > 256 * 32 / WAVES_PER_GROUP) groups = 256 * 32 / WAVES_PER_GROUP;
     if (sc.lds_nodes >= sc.n_nodes)
         hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
                            rp, sp, d_radiance);

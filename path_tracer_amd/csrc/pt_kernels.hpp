@@ -11,13 +11,13 @@ struct RenderParams {
     unsigned long long *stats;   // PT_STATS builds only: 8 counters {steps, active lanes} x {SPLIT, LEAF, HIT, END}
 };
 
-// Work distribution of the path kernel: persistent waves draw (piece, tile) items from
-// one counter, piece-major.  A piece is a contiguous run of `piece_len` sample indices;
+// Work distribution of the path kernel: one wave per (piece, tile) item, items handed out
+// piece-major through one ticket counter in the order the workgroups start.  A piece is a contiguous run of `piece_len` sample indices;
 // piece k of a tile continues the per-pixel sums piece k-1 left in the radiance buffer
 // (same sequential fp32 order as one long run) and therefore waits for done[tile] >= k.
 struct SchedParams {
     int32_t n_tiles, n_pieces, piece_len;
-    int32_t *ctrl;        // [0] next item, [1] error flag (a dependency wait gave up)
+    int32_t *ctrl;        // [0] next ticket, [1] error flag (a dependency wait gave up)
     int32_t *done;        // per tile: pieces completed
 };
 
