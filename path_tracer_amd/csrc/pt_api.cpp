@@ -496,6 +496,7 @@ int pt_render(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begi
         // the kernel's bounded dependency wait (pt_kernels.hip) reports here instead of hanging
         int32_t ctrl[2] = {0, 0};
         PT_HIP(c, hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost));
+        if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
         if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
     }
     return PT_OK;

@@ -86,15 +86,22 @@ template <bool ALL_IN_LDS>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
                                                                     float *radiance)
 {
+    // dynamic LDS: n0[0 .. lds_nodes) then the group's ticket.  There is no static __shared__
+    // in this kernel, so the array starts at LDS address 0 and 16 * slot IS the LDS address of
+    // a node's n0 entry: no base add per node visit (checked below: error flag 2).
     extern __shared__ float4 lds_n0[];
-    __shared__ int ticket;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f lds_f4;
+    auto lds_read = [](uint32_t addr) -> float4 { const v4f t = *(lds_f4 *)(uintptr_t)addr; return make_float4(t.x, t.y, t.z, t.w); };
     // One ticket per workgroup, drawn while the nodes are staged: the group's waves take the
     // (piece, tile) items 4*ticket .. 4*ticket+3.  Tickets follow the order in which groups
     // START, so the item a wave may have to wait for (same tile, previous piece: a lower
     // item) belongs to a group that is already running or done -- whatever order the
     // hardware dispatches blockIdx in.
-    if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
+    if ((uint32_t)(uintptr_t)lds_n0 != 0u) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return; }
     const int lds_nodes = sc.lds_nodes;
+    int &ticket = *(int *)&lds_n0[lds_nodes];
+    if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
     for (int i = threadIdx.x; i < lds_nodes; i += 64 * WAVES_PER_GROUP) lds_n0[i] = sc.n0[i];
     __syncthreads();
 
@@ -166,8 +173,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         const int off = code_index(c) << 4;
         const auto raw = __builtin_amdgcn_raw_buffer_load_b128(n1_rsrc, off, 0, 0);
         n1 = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
-        if (ALL_IN_LDS) n0 = *(const float4 *)((const char *)lds_n0 + off);
-        else if (off < (lds_nodes << 4)) { n0 = *(const float4 *)((const char *)lds_n0 + off); asm volatile("" : "+v"(n0.x)); }
+        if (ALL_IN_LDS) n0 = lds_read((uint32_t)off);
+        else if (off < (lds_nodes << 4)) { n0 = lds_read((uint32_t)off); asm volatile("" : "+v"(n0.x)); }
         else n0 = *(const float4 *)((const char *)sc.n0 + off);
     };
     auto lanes = [&](bool p) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(p))); };
@@ -381,7 +388,7 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     if (e != hipSuccess) return e;
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
-    const size_t lds_bytes = (size_t)sc.lds_nodes * sizeof(float4);
+    const size_t lds_bytes = ((size_t)sc.lds_nodes + 1) * sizeof(float4);   // + the ticket word
     if (sc.lds_nodes >= sc.n_nodes)
         hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
                            rp, sp, d_radiance);
