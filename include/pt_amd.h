@@ -157,6 +157,13 @@ float pt_last_path_kernel_ms(pt_context *ctx);
 int pt_set_lanes_per_pixel(pt_context *ctx, int32_t lanes);
 int pt_get_lanes_per_pixel(const pt_context *ctx, int32_t samples, int32_t sample_begin, int32_t sample_end);
 
+/* Self-test, no counterpart in the reference: runs the library's short forms of 1/x (fn 0),
+ * sqrt(x) (fn 1) and 1/sqrt(x) (fn 2) -- the three unary fp32 operations of vec.rs:38-44,95-97,
+ * scene/mod.rs:31, sphere.rs:54 -- over ALL 2^32 fp32 inputs on the GPU against the correctly
+ * rounded IEEE operation and returns the number of inputs whose result differs (NaN payloads
+ * aside).  The library relies on this being 0. */
+int pt_selftest_unary(pt_context *ctx, int32_t fn, uint64_t *mismatches);
+
 /* ---- host-side helpers (pure CPU, no GPU needed) ------------------------- */
 
 /* BvhNode::construct + pre-order flatten (src/scene/bvh.rs:13-91).  Returns the

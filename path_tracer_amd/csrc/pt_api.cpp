@@ -381,6 +381,23 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
     return PT_OK;
 }
 
+int pt_selftest_unary(pt_context *c, int32_t fn, uint64_t *mismatches)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (fn < 0 || fn > 2 || !mismatches) return fail(c, PT_ERR_INVALID, "pt_selftest_unary: fn must be 0, 1 or 2 and mismatches non-NULL");
+    PT_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_count = nullptr, h_count = 0;
+    PT_HIP(c, hipMalloc((void **)&d_count, sizeof h_count));
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof h_count, c->stream);
+    if (e == hipSuccess) e = ptk::launch_unary_selftest(fn, d_count, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_count);
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, "pt_selftest_unary failed: %s", hipGetErrorString(e));
+    *mismatches = h_count;
+    return PT_OK;
+}
+
 int pt_set_lanes_per_pixel(pt_context *c, int32_t lanes)
 {
     if (!c) return PT_ERR_INVALID;

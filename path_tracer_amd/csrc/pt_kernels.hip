@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             }
         }
         if (new_walk) {
-            inv = fill(1.0f) / ray.d;                                            // scene/mod.rs:31
+            inv = mk(p_rcp(ray.d.x), p_rcp(ray.d.y), p_rcp(ray.d.z));            // scene/mod.rs:31: (1,1,1) / dir
             regular = finite3(inv) && finite3(ray.o);
             a = dot(ray.d, ray.d);                                               // sphere.rs:49
             h.t = T_MAX; h.prim = -1;
@@ -342,9 +342,35 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
     rgb8[3 * i + 2] = trunc_sat_u8(c.z);
 }
 
+// pt_selftest_unary: one fp32 bit pattern per lane
+template <int FN>
+__global__ __launch_bounds__(256) void unary_selftest_kernel(unsigned long long *count, uint32_t base)
+{
+    const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
+    const float x = __uint_as_float(bits);
+    float ref, got;
+    if (FN == 0) { ref = 1.0f / x; got = p_rcp(x); }
+    else if (FN == 1) { ref = __builtin_sqrtf(x); got = p_sqrt(x); }
+    else { ref = 1.0f / __builtin_sqrtf(x); got = rsq(x); }
+    const bool same = (ref != ref && got != got) || __float_as_uint(ref) == __float_as_uint(got);
+    const unsigned long long bad = __ballot(!same);
+    if (bad != 0ull && (threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)__popcll(bad));
+}
+
 }  // namespace
 
 namespace ptk {
+
+hipError_t launch_unary_selftest(int fn, unsigned long long *d_count, hipStream_t stream)
+{
+    for (uint64_t base = 0; base < (1ull << 32); base += (1ull << 28)) {
+        const dim3 grid((1u << 28) / 256u), block(256);
+        if (fn == 0) hipLaunchKernelGGL(unary_selftest_kernel<0>, grid, block, 0, stream, d_count, (uint32_t)base);
+        else if (fn == 1) hipLaunchKernelGGL(unary_selftest_kernel<1>, grid, block, 0, stream, d_count, (uint32_t)base);
+        else hipLaunchKernelGGL(unary_selftest_kernel<2>, grid, block, 0, stream, d_count, (uint32_t)base);
+    }
+    return hipGetLastError();
+}
 
 int tiles_for(const Camera &cam, int lanes)
 {

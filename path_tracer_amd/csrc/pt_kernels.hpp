@@ -23,6 +23,8 @@ struct SchedParams {
 
 namespace ptk {
 int tiles_for(const ptd::Camera &cam, int lanes);
+// counts, into *d_count, the fp32 bit patterns for which short form `fn` differs from the IEEE operation
+hipError_t launch_unary_selftest(int fn, unsigned long long *d_count, hipStream_t stream);
 hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
                        float *d_radiance, hipStream_t stream);
 size_t sched_bytes(const ptd::Camera &cam);

@@ -114,6 +114,13 @@ class ParallelRenderer:
     def last_path_kernel_ms(self):
         return float(_abi.lib().pt_last_path_kernel_ms(self._ctx))
 
+    def selftest_unary(self, fn):
+        """pt_selftest_unary: inputs (of all 2^32) on which short form `fn` (0: 1/x, 1: sqrt,
+        2: 1/sqrt) differs from the IEEE operation."""
+        n = C.c_uint64(0)
+        _abi.check(self._ctx, _abi.lib().pt_selftest_unary(self._ctx, int(fn), C.byref(n)))
+        return int(n.value)
+
 
 class Raytracer:
     """raytracer.rs:29-44: camera + scene + samples; ``new`` builds the BVH

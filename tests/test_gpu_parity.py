@@ -284,3 +284,11 @@ def test_cfg1_frame_against_oracle(renderer, oracle):
     assert tonemapped_agreement(osc, rad, seq, 10) >= 0.999
     tm = lambda r: np.sqrt(r / np.float32(100.0))
     assert float(np.sqrt(np.mean((tm(rad) - tm(seq)) ** 2))) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fn", [0, 1, 2], ids=["rcp", "sqrt", "rsq"])
+def test_unary_short_forms(renderer, fn):
+    """The library's 6-10 instruction forms of 1/x, sqrt(x), 1/sqrt(x) (pt_device.hpp) return the
+    correctly rounded IEEE result for every one of the 2^32 fp32 inputs (bit-exact bar)."""
+    assert renderer.selftest_unary(fn) == 0
