@@ -268,9 +268,8 @@ PTD float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r)
 PTD float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 PTD float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-PTD float vmed3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// first operand wave-uniform (a constant): read from an SGPR, no per-step v_mov
-PTD float vmed3_s(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c)); return r; }
+// one v_med3_f32 (no canonicalising v_max; constants come from SGPRs)
+PTD float vmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
 // AABB::intersect (aabb.rs:25-36) for the Split whose data is (n0, n1); returns the next code.
 // REGULAR (no NaN anywhere): with lo_k = min(v0.k, v1.k), hi_k = max(v0.k, v1.k) the test is
@@ -286,7 +285,7 @@ PTD int32_t split_step(const float4 n0, const float4 n1, const f3 o, const f3 in
     f3 v1 = (mk(n1.x, n1.y, n1.z) - o) * inv;
     float tmin, tmax;
     if (REGULAR) {
-        tmin = vmed3(vmed3(vmed3_s(T_MIN, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
+        tmin = vmed3(vmed3(vmed3(T_MIN, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
         tmax = vmed3(vmed3(vmed3(closest, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
     } else {
         float mnx = sse_min(v0.x, v1.x), mny = sse_min(v0.y, v1.y), mnz = sse_min(v0.z, v1.z);

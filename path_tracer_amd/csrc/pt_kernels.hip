@@ -228,6 +228,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             if (pick == ST_SPLIT) {
                 const bool all_regular = __ballot((uint32_t)code < (uint32_t)n_nodes && !regular) == 0ull;
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
+#ifdef PT_SPLIT_LOOP_OLD
                 bool at_split = (uint32_t)code < (uint32_t)n_nodes;
                 do {
                     PT_STAT(0, lanes(at_split));
@@ -239,6 +240,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                     }
                     at_split = (uint32_t)code < (uint32_t)n_nodes;
                 } while (lanes(at_split) >= keep && keep > 0);
+#else
+                // the lanes at a Split stay in the loop (exec shrinks as they leave the state);
+                // the run ends for all of them once fewer than `keep` are left
+                if ((uint32_t)code < (uint32_t)n_nodes) {
+                    if (all_regular) {
+                        for (;;) {
+                            PT_STAT(0, lanes(true));
+                            float4 n0, n1;
+                            fetch(code, n0, n1);
+                            code = split_step<true>(n0, n1, ray.o, inv, h.t);
+                            const bool at = (uint32_t)code < (uint32_t)n_nodes;
+                            const bool few = lanes(at) < keep;
+                            if ((int)!at | (int)few) break;
+                        }
+                    } else {
+                        for (;;) {
+                            PT_STAT(0, lanes(true));
+                            float4 n0, n1;
+                            fetch(code, n0, n1);
+                            code = split_step<false>(n0, n1, ray.o, inv, h.t);
+                            const bool at = (uint32_t)code < (uint32_t)n_nodes;
+                            const bool few = lanes(at) < keep;
+                            if ((int)!at | (int)few) break;
+                        }
+                    }
+                }
+#endif
                 PT_TIME(0);
             } else if (pick == ST_LEAF) {
                 PT_STAT(1, cL);
