@@ -446,10 +446,10 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
         unsigned long long hs[16];
         (void)hipMemcpyAsync(hs, d_stats, 128, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
-        const char *nm[4] = {"SPLIT", "LEAF", "HIT", "END"};
+        const char *nm[4] = {"SPLIT", "LEAF", "SHADE:hit", "SHADE:end"};
         for (int k = 0; k < 4; k++)
             fprintf(stderr, "[pt stats] %-5s steps %llu  lanes/step %.1f\n", nm[k], hs[2 * k], hs[2 * k] ? (double)hs[2 * k + 1] / hs[2 * k] : 0.0);
-        const char *tn[6] = {"SPLIT", "LEAF", "HIT", "END", "vote", "tails"};
+        const char *tn[6] = {"SPLIT", "LEAF", "SHADE:hit", "SHADE:end", "vote", "tails"};
         double tot = 0;
         for (int k = 0; k < 6; k++) tot += (double)hs[8 + k];
         for (int k = 0; k < 6; k++)

@@ -39,8 +39,9 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 // only that state's step, predicated on the lanes in it:
 //   SPLIT  one AABB::intersect of the walk           (aabb.rs:25-36)
 //   LEAF   one Sphere::trace of the walk             (sphere.rs:46-69)
-//   HIT    Sphere::record + Material::scatter        (sphere.rs:37-42, material/*.rs)
-//   END    sky, accumulate, next sample's camera ray (raytracer.rs:67-70,88,77-85)
+//   SHADE  the walk has ended: Sphere::record + Material::scatter on a hit (sphere.rs:37-42,
+//          material/*.rs); sky, accumulate, next sample's camera ray when the path ends
+//          (raytracer.rs:67-70,88,77-85)
 // A lane whose path or walk ends never idles until the longest one of the wave
 // ends, and box tests / sphere tests / shading are not serialised against each
 // other inside one iteration.  Each lane still executes exactly the reference's
@@ -54,20 +55,18 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #ifndef PT_ITEMS_PER_SLOT
 #define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
 #endif
+// vote weights: a SHADE step is the most expensive one, so it waits for more lanes
 #ifndef PT_W_SPLIT
-#define PT_W_SPLIT 1
+#define PT_W_SPLIT 4
 #endif
 #ifndef PT_W_LEAF
-#define PT_W_LEAF 2
+#define PT_W_LEAF 8
 #endif
-#ifndef PT_W_HIT
-#define PT_W_HIT 1
-#endif
-#ifndef PT_W_END
-#define PT_W_END 1
+#ifndef PT_W_SHADE
+#define PT_W_SHADE 1
 #endif
 
-enum : int { ST_SPLIT = 0, ST_LEAF = 1, ST_HIT = 2, ST_END = 3, ST_DONE = 4 };
+enum : int { ST_SPLIT = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
 
 // Workgroup = 4 waves that share one LDS copy of n0[0 .. lds_nodes) (the top of the
 // tree, breadth-first) and are otherwise independent: one tile each.  n1[] is read
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     // Per-lane state.  `code` is the whole control state of the lane: a node code while
     // the walk stands on a node (Split: [0, n_nodes), Leaf: sign bit set), n_nodes when
     // the walk has just ended, and three values above it for the other states.
-    const int32_t C_HIT = n_nodes + 1, C_END = n_nodes + 2, C_DONE = n_nodes + 3;
+    const int32_t C_DONE = n_nodes + 1;
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
     f3 inv = fill(0.0f);
     float a = 0.0f;
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     f3 att = fill(1.0f);
     int bounce = 0;
     uint64_t rng = 0;
-    bool regular = true, to_sky = true;
+    bool regular = true;
 
     // n1[i] through the L1 (one 32-bit byte offset serves both arrays), n0[i] from LDS when staged
     auto fetch = [&](int32_t c, float4 &n0, float4 &n1) {
@@ -215,32 +214,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
 
         int pick;
         for (;;) {
-            if (code == n_nodes) { code = h.prim >= 0 ? C_HIT : C_END; to_sky = true; }   // walk ended
             const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
-            const int cH = lanes(code == C_HIT), cE = lanes(code == C_END);
+            const int cZ = lanes(code == n_nodes);                               // walk ended: to be shaded
             int top = cS * PT_W_SPLIT, v;
             pick = ST_SPLIT;
-            v = cL * PT_W_LEAF; if (v > top) { top = v; pick = ST_LEAF; }
-            v = cH * PT_W_HIT;  if (v > top) { top = v; pick = ST_HIT; }
-            v = cE * PT_W_END;  if (v > top) { top = v; pick = ST_END; }
+            v = cL * PT_W_LEAF;  if (v > top) { top = v; pick = ST_LEAF; }
+            v = cZ * PT_W_SHADE; if (v > top) { top = v; pick = ST_SHADE; }
             if (top == 0) pick = ST_DONE;
             PT_TIME(4);
             if (pick == ST_SPLIT) {
                 const bool all_regular = __ballot((uint32_t)code < (uint32_t)n_nodes && !regular) == 0ull;
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
-#ifdef PT_SPLIT_LOOP_OLD
-                bool at_split = (uint32_t)code < (uint32_t)n_nodes;
-                do {
-                    PT_STAT(0, lanes(at_split));
-                    if (at_split) {
-                        float4 n0, n1;
-                        fetch(code, n0, n1);
-                        code = all_regular ? split_step<true>(n0, n1, ray.o, inv, h.t)
-                                           : split_step<false>(n0, n1, ray.o, inv, h.t);
-                    }
-                    at_split = (uint32_t)code < (uint32_t)n_nodes;
-                } while (lanes(at_split) >= keep && keep > 0);
-#else
                 // the lanes at a Split stay in the loop (exec shrinks as they leave the state);
                 // the run ends for all of them once fewer than `keep` are left
                 if ((uint32_t)code < (uint32_t)n_nodes) {
@@ -266,7 +250,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                         }
                     }
                 }
-#endif
                 PT_TIME(0);
             } else if (pick == ST_LEAF) {
                 PT_STAT(1, cL);
@@ -281,25 +264,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         }
         if (pick == ST_DONE) break;
 
-        if (pick == ST_HIT) {
-            PT_STAT(2, lanes(code == C_HIT));
-            if (code == C_HIT) {
-                // one hit iteration of `for _ in 0..MAX_TRACES` (raytracer.rs:52-61)
+        // SHADE: the lanes whose walk has ended.  A hit scatters (one iteration of
+        // `for _ in 0..MAX_TRACES`, raytracer.rs:52-61) and usually starts the next walk; a miss,
+        // an absorbed path or the bounce cap ends the path in the same step.
+        {
+            const bool walked = code == n_nodes;
+            bool ended = walked && h.prim < 0, to_sky = true;
+            PT_STAT(2, lanes(walked && h.prim >= 0));
+            if (walked && h.prim >= 0) {
                 f3 am; Ray nr;
                 if (scatter(sc, ray, h, rng, am, nr)) {
                     att = att * am;                                              // raytracer.rs:57
                     ray = nr;
                     bounce++;
-                    if (bounce >= 5) { code = C_END; to_sky = true; }            // MAX_TRACES, raytracer.rs:48
+                    if (bounce >= 5) ended = true;                               // MAX_TRACES, raytracer.rs:48
                     else new_walk = true;
                 } else {
-                    code = C_END; to_sky = false;                                // raytracer.rs:60: return 0
+                    ended = true; to_sky = false;                                // raytracer.rs:60: return 0
                 }
             }
             PT_TIME(2);
-        } else {
-            PT_STAT(3, lanes(code == C_END));
-            if (code == C_END) {
+            PT_STAT(3, lanes(ended));
+            if (ended) {
                 f3 color = fill(0.0f);
                 if (to_sky) color = sky(ray, att);                               // raytracer.rs:67-70
                 sum = sum + color;                                               // raytracer.rs:88
