@@ -66,7 +66,6 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #define PT_W_SHADE 1
 #endif
 
-enum : int { ST_SPLIT = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
 
 // Workgroup = 4 waves that share one LDS copy of n0[0 .. lds_nodes) (the top of the
 // tree, breadth-first) and are otherwise independent: one tile each.  n1[] is read
@@ -212,21 +211,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         new_path = false; new_walk = false;
         PT_TIME(5);
 
-        int pick;
+        // every ray of the wave REGULAR (pt_device.hpp)?  Re-evaluated once per SHADE step; a lane
+        // whose irregular walk is over keeps the wave on the general slab test until its next walk
+        const bool all_regular = __ballot(!regular) == 0ull;
+        bool done = false;
         for (;;) {
             const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
             const int cZ = lanes(code == n_nodes);                               // walk ended: to be shaded
-            int top = cS * PT_W_SPLIT, v;
-            pick = ST_SPLIT;
-            v = cL * PT_W_LEAF;  if (v > top) { top = v; pick = ST_LEAF; }
-            v = cZ * PT_W_SHADE; if (v > top) { top = v; pick = ST_SHADE; }
-            if (top == 0) pick = ST_DONE;
+            const int vS = cS * PT_W_SPLIT, vL = cL * PT_W_LEAF, vZ = cZ * PT_W_SHADE;
             PT_TIME(4);
-            if (pick == ST_SPLIT) {
-                const bool all_regular = __ballot((uint32_t)code < (uint32_t)n_nodes && !regular) == 0ull;
+            if (vS >= vL && vS >= vZ) {
+                if (vS == 0) { done = true; break; }                             // no lane has work left
+                // SPLIT run: the lanes at a Split stay in the loop (exec shrinks as they leave the
+                // state); the run ends for all of them once fewer than `keep` are left
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
-                // the lanes at a Split stay in the loop (exec shrinks as they leave the state);
-                // the run ends for all of them once fewer than `keep` are left
                 if ((uint32_t)code < (uint32_t)n_nodes) {
                     if (all_regular) {
                         for (;;) {
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                     }
                 }
                 PT_TIME(0);
-            } else if (pick == ST_LEAF) {
+            } else if (vL >= vZ) {
                 PT_STAT(1, cL);
                 if (code < 0) {
                     float4 n0, n1;
@@ -262,7 +260,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 PT_TIME(1);
             } else break;
         }
-        if (pick == ST_DONE) break;
+        if (done) break;
 
         // SHADE: the lanes whose walk has ended.  A hit scatters (one iteration of
         // `for _ in 0..MAX_TRACES`, raytracer.rs:52-61) and usually starts the next walk; a miss,
