@@ -286,8 +286,8 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     if ((int32_t)order.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
     // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
     auto code_of = [&](int32_t i) -> int32_t {
-        if (i >= n_nodes) return n_nodes;
-        return nodes[i].prim >= 0 ? (int32_t)((uint32_t)slot[i] | 0x80000000u) : slot[i];
+        if (i >= n_nodes) return n_nodes << PT_CODE_SHIFT;
+        return nodes[i].prim >= 0 ? (int32_t)((uint32_t)(slot[i] << PT_CODE_SHIFT) | 0x80000000u) : (slot[i] << PT_CODE_SHIFT);
     };
     float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_nodes;
     for (int32_t i = 0; i < n_nodes; i++) {

@@ -234,8 +234,8 @@ PTD f3 sphere_uv_color(const Scene &sc, int tex, f3 n)                          
 
 // ---- Scene::trace (scene/mod.rs:24-34) over the flattened BvhNode tree ---------
 //
-// A node CODE is the node's slot in the arrays n0[], n1[] with the sign bit set
-// when the node is a Leaf; the code n_nodes (no flag) ends the walk.  Slots are
+// A node CODE is the byte offset (16 * slot) of the node in the arrays n0[], n1[] with the
+// sign bit set when the node is a Leaf; the code 16 * n_nodes (no flag) ends the walk.  Slots are
 // numbered breadth-first (top of the tree first); the walk does not depend on
 // the numbering, it follows the codes stored in the nodes:
 //          n0[slot]                                   n1[slot]
@@ -258,7 +258,12 @@ constexpr int32_t LEAF_BIT = (int32_t)0x80000000;
 
 struct Hit { float t; int32_t prim; };
 
-PTD int code_index(int32_t code) { return code & 0x7fffffff; }
+// codes count in units of 2^-PT_CODE_SHIFT slots: 4 = byte offsets (no shift per node visit)
+#ifndef PT_CODE_SHIFT
+#define PT_CODE_SHIFT 4
+#endif
+PTD int code_index(int32_t code) { return (code & 0x7fffffff) >> PT_CODE_SHIFT; }
+PTD int code_offset(int32_t code) { return (code & 0x7fffffff) << (4 - PT_CODE_SHIFT); }
 
 // One-instruction IEEE min/max.  Only used where no operand can be NaN (REGULAR
 // rays), where they equal both _mm_min_ps/_mm_max_ps and Rust's f32::min/max;
@@ -328,7 +333,7 @@ PTD Hit scene_trace(const Scene &sc, const Ray &ray)
     const float a = dot(ray.d, ray.d);                                           // sphere.rs:49
     Hit h; h.t = T_MAX; h.prim = -1;
     int32_t code = sc.root_code;
-    while (code_index(code) < sc.n_nodes) {
+    while (code_index(code) < sc.n_nodes) {   // code_index(end code) == n_nodes
         const int i = code_index(code);
         const float4 n0 = sc.n0[i], n1 = sc.n1[i];
         if (code < 0) { leaf_step(n0, n1, ray.o, ray.d, a, h); code = __float_as_int(n1.w); }

@@ -111,9 +111,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     const int slot = lane % P, chunk = lane / P;
     const int tiles_x = (cam.width + tw - 1) / tw;
     const int S = rp.S;
-    const int n_nodes = sc.n_nodes;
+    const int n_nodes = sc.n_nodes << PT_CODE_SHIFT;   // in code units: the code that ends a walk
     const int n_items = sched.n_tiles * sched.n_pieces;
-    const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, n_nodes * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, sc.n_nodes * 16, 0x00020000);
 
   // A wave renders ONE item: a tile's pixels x a contiguous piece of the sample indices.
   // Fine-grained items keep every SIMD's wave slots full until the very end of the frame (a
@@ -167,8 +167,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     bool regular = true;
 
     // n1[i] through the L1 (one 32-bit byte offset serves both arrays), n0[i] from LDS when staged
-    auto fetch = [&](int32_t c, float4 &n0, float4 &n1) {
-        const int off = code_index(c) << 4;
+    // SPLIT_ONLY: the caller knows c is a Split code (no Leaf flag to mask)
+    auto fetch = [&](int32_t c, float4 &n0, float4 &n1, const bool SPLIT_ONLY = false) {
+        const int off = SPLIT_ONLY ? (c << (4 - PT_CODE_SHIFT)) : code_offset(c);
         const auto raw = __builtin_amdgcn_raw_buffer_load_b128(n1_rsrc, off, 0, 0);
         n1 = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
         if (ALL_IN_LDS) n0 = lds_read((uint32_t)off);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                         for (;;) {
                             PT_STAT(0, lanes(true));
                             float4 n0, n1;
-                            fetch(code, n0, n1);
+                            fetch(code, n0, n1, true);
                             code = split_step<true>(n0, n1, ray.o, inv, h.t);
                             const bool at = (uint32_t)code < (uint32_t)n_nodes;
                             const bool few = lanes(at) < keep;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                         for (;;) {
                             PT_STAT(0, lanes(true));
                             float4 n0, n1;
-                            fetch(code, n0, n1);
+                            fetch(code, n0, n1, true);
                             code = split_step<false>(n0, n1, ray.o, inv, h.t);
                             const bool at = (uint32_t)code < (uint32_t)n_nodes;
                             const bool few = lanes(at) < keep;
