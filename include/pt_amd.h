@@ -163,6 +163,11 @@ int pt_get_lanes_per_pixel(const pt_context *ctx, int32_t samples, int32_t sampl
  * rounded IEEE operation and returns the number of inputs whose result differs (NaN payloads
  * aside).  The library relies on this being 0. */
 int pt_selftest_unary(pt_context *ctx, int32_t fn, uint64_t *mismatches);
+/* Self-test, no counterpart in the reference: the sample-grid coordinates u, v of
+ * raytracer.rs:77-85 for EVERY (pixel column, sx) and (pixel row, sy) of the current camera at
+ * `samples`, computed the way the path kernel does (reciprocal + fused corrections) against the
+ * IEEE divisions of the reference; returns the number that differ.  The library relies on 0. */
+int pt_selftest_grid(pt_context *ctx, int32_t samples, uint64_t *mismatches);
 
 /* ---- host-side helpers (pure CPU, no GPU needed) ------------------------- */
 

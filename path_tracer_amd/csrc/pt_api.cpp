@@ -398,6 +398,26 @@ int pt_selftest_unary(pt_context *c, int32_t fn, uint64_t *mismatches)
     return PT_OK;
 }
 
+int pt_selftest_grid(pt_context *c, int32_t samples, uint64_t *mismatches)
+{
+    int rc = check_ready(c, samples);
+    if (rc != PT_OK) return rc;
+    if (!mismatches) return fail(c, PT_ERR_INVALID, "pt_selftest_grid: mismatches is NULL");
+    PT_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_count = nullptr, h_count = 0;
+    PT_HIP(c, hipMalloc((void **)&d_count, sizeof h_count));
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof h_count, c->stream);
+    if (e == hipSuccess)
+        e = ptk::launch_grid_selftest(c->camera.width, c->camera.height, samples, 1.0f / (float)(samples - 1),
+                                      1.0f / (float)c->camera.width, 1.0f / (float)c->camera.height, d_count, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_count);
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, "pt_selftest_grid failed: %s", hipGetErrorString(e));
+    *mismatches = h_count;
+    return PT_OK;
+}
+
 int pt_set_lanes_per_pixel(pt_context *c, int32_t lanes)
 {
     if (!c) return PT_ERR_INVALID;
@@ -430,6 +450,9 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     rp.s1 = sample_end;
     rp.lanes = pick_lanes(c, sample_end - sample_begin);
     rp.accumulate = accumulate ? 1 : 0;
+    rp.inv_s1 = 1.0f / (float)(samples - 1);
+    rp.inv_w = 1.0f / (float)c->camera.width;
+    rp.inv_h = 1.0f / (float)c->camera.height;
     rp.stats = nullptr;
 #ifdef PT_STATS
     static unsigned long long *d_stats = nullptr;

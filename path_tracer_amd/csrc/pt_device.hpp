@@ -216,6 +216,35 @@ PTD Ray sample_ray(const Camera &c, int S, int px, int py, int s)
     return camera_ray(c, u, v);
 }
 
+// x / a from ra = RN(1/a) (correctly rounded reciprocal): a product and two fused residual
+// corrections instead of the 12-instruction IEEE expansion.  Correctly rounded for every x, a
+// whose quotient and residuals stay normal and whose a is not 2^24-1 ulps (all-ones mantissa):
+//   q0 = RN(x*ra) is within 2 ulp of x/a;  q1 = RN(q0 + r0*ra) is one of the two floats around
+//   x/a, so r1 = x - a*q1 is exact;  V = q1 + r1*ra = x/a + (x/a - q1)*eps, |eps| < 2^-24, and
+//   no rounding boundary m of the quotient can lie between V and x/a because
+//   |x/a - m| >= ulp(m)/2 / A with A = a's integer mantissa <= 2^24 - 2   (Markstein 1990).
+// Used only for the sample grid of trace_pixel, whose divisors are S-1, W and H (small integers)
+// and whose dividends are 0 or >= 1; pt_selftest_grid compares every grid coordinate of a frame
+// size with the IEEE divisions (tests/test_gpu_parity.py::test_sample_grid_division).
+PTD float div_by(float x, float a, float ra)
+{
+    float q = x * ra;
+    float r = __builtin_fmaf(-a, q, x);
+    q = __builtin_fmaf(r, ra, q);
+    r = __builtin_fmaf(-a, q, x);
+    return __builtin_fmaf(r, ra, q);
+}
+// sample (sx, sy) of the grid of raytracer.rs:77-86 with the three divisions through div_by
+PTD Ray sample_ray_grid(const Camera &c, int S, float inv_s1, float inv_w, float inv_h, int px, int py, int sx, int sy)
+{
+    const float s1 = (float)(S - 1);
+    float x = (float)px + div_by((float)sx, s1, inv_s1);
+    float u = div_by(x, (float)c.width, inv_w);
+    float y = (float)py + div_by((float)sy, s1, inv_s1);
+    float v = 1.0f - div_by(y, (float)c.height, inv_h);
+    return camera_ray(c, u, v);
+}
+
 PTD f3 sphere_uv_color(const Scene &sc, int tex, f3 n)                           // sphere.rs:6-18 + picture.rs:17-38
 {
     float phi = p_atan2f(n.z, n.x);

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     int s = ps0 + chunk * per;
     int s_end = s + per < ps1 ? s + per : ps1;
     if (!valid) s_end = s;
+    // grid coordinates of sample s, kept incrementally: (sx << 16) | sy, s = sx * S + sy (sx outer)
+    uint32_t sxy = ((uint32_t)(s / S) << 16) | (uint32_t)(s % S);
     const bool resume = rp.accumulate || piece > 0;
 
     if (piece > 0) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         if (new_path) {
             if (s >= s_end) code = C_DONE;
             else {
-                ray = sample_ray(cam, S, px, py, s);                             // raytracer.rs:77-85
+                ray = sample_ray_grid(cam, S, rp.inv_s1, rp.inv_w, rp.inv_h, px, py, (int)(sxy >> 16), (int)(sxy & 0xffffu));   // raytracer.rs:77-85
                 att = fill(1.0f);                                                // raytracer.rs:50
                 bounce = 0;
                 rng = path_rng(rp.seed, pixel, (uint32_t)s);
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 if (to_sky) color = sky(ray, att);                               // raytracer.rs:67-70
                 sum = sum + color;                                               // raytracer.rs:88
                 s++;
+                sxy++;
+                if ((sxy & 0xffffu) == (uint32_t)S) sxy += 0x10000u - (uint32_t)S;
                 new_path = true;
             }
             PT_TIME(3);
@@ -370,9 +374,36 @@ __global__ __launch_bounds__(256) void unary_selftest_kernel(unsigned long long 
     if (bad != 0ull && (threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)__popcll(bad));
 }
 
+// pt_selftest_grid: lane = (pixel coordinate p, grid coordinate g); axis 0 = columns (u), 1 = rows (v)
+__global__ __launch_bounds__(256) void grid_selftest_kernel(unsigned long long *count, int extent, int S, float inv_s1,
+                                                            float inv_extent, int axis)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < (long long)extent * S) {
+        const int p = (int)(i / S), g = (int)(i % S);
+        const float s1 = (float)(S - 1);
+        const float ref_f = (float)p + ((float)g / s1), got_f = (float)p + div_by((float)g, s1, inv_s1);
+        float ref = ref_f / (float)extent, got = div_by(got_f, (float)extent, inv_extent);
+        if (axis == 1) { ref = 1.0f - ref; got = 1.0f - got; }
+        bad = __float_as_uint(ref_f) != __float_as_uint(got_f) || __float_as_uint(ref) != __float_as_uint(got);
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
 }  // namespace
 
 namespace ptk {
+
+hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, float inv_w, float inv_h, unsigned long long *d_count,
+                                hipStream_t stream)
+{
+    const long long nu = (long long)width * S, nv = (long long)height * S;
+    hipLaunchKernelGGL(grid_selftest_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, stream, d_count, width, S, inv_s1, inv_w, 0);
+    hipLaunchKernelGGL(grid_selftest_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, d_count, height, S, inv_s1, inv_h, 1);
+    return hipGetLastError();
+}
 
 hipError_t launch_unary_selftest(int fn, unsigned long long *d_count, hipStream_t stream)
 {

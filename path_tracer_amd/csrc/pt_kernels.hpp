@@ -8,6 +8,7 @@ struct RenderParams {
     int32_t s0, s1;       // sample-index range [s0, s1) rendered by this launch
     int32_t lanes;        // lanes per pixel: power of two in [1, 64]
     int32_t accumulate;   // continue the sum already in the radiance buffer
+    float inv_s1, inv_w, inv_h;   // 1/(S-1), 1/W, 1/H: correctly rounded fp32 reciprocals (host), for div_by
     unsigned long long *stats;   // PT_STATS builds only: 8 counters {steps, active lanes} x {SPLIT, LEAF, HIT, END}
 };
 
@@ -25,6 +26,8 @@ namespace ptk {
 int tiles_for(const ptd::Camera &cam, int lanes);
 // counts, into *d_count, the fp32 bit patterns for which short form `fn` differs from the IEEE operation
 hipError_t launch_unary_selftest(int fn, unsigned long long *d_count, hipStream_t stream);
+hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, float inv_w, float inv_h, unsigned long long *d_count,
+                                hipStream_t stream);
 hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
                        float *d_radiance, hipStream_t stream);
 size_t sched_bytes(const ptd::Camera &cam);

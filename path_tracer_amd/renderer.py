@@ -114,6 +114,13 @@ class ParallelRenderer:
     def last_path_kernel_ms(self):
         return float(_abi.lib().pt_last_path_kernel_ms(self._ctx))
 
+    def selftest_grid(self, samples):
+        """pt_selftest_grid for the bound camera: sample-grid coordinates that differ from the
+        reference's IEEE divisions (must be 0)."""
+        n = C.c_uint64(0)
+        _abi.check(self._ctx, _abi.lib().pt_selftest_grid(self._ctx, int(samples), C.byref(n)))
+        return int(n.value)
+
     def selftest_unary(self, fn):
         """pt_selftest_unary: inputs (of all 2^32) on which short form `fn` (0: 1/x, 1: sqrt,
         2: 1/sqrt) differs from the IEEE operation."""

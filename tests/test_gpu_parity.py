@@ -292,3 +292,14 @@ def test_unary_short_forms(renderer, fn):
     """The library's 6-10 instruction forms of 1/x, sqrt(x), 1/sqrt(x) (pt_device.hpp) return the
     correctly rounded IEEE result for every one of the 2^32 fp32 inputs (bit-exact bar)."""
     assert renderer.selftest_unary(fn) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,samples", [((1920, 1080), 64), ((1920, 1080), 16), ((3840, 2160), 32), ((400, 225), 10),
+                                           ((1023, 767), 7), ((16, 9), 2), ((8191, 4099), 33)])
+def test_sample_grid_division(renderer, size, samples):
+    """Every sample-grid coordinate (raytracer.rs:77-85) of these frame sizes, computed through the
+    reciprocal + fused corrections of the path kernel, equals the IEEE divisions bit for bit."""
+    rt = make_raytracer("simple", size[0], size[1], samples)
+    renderer.bind(rt)
+    assert renderer.selftest_grid(samples) == 0
