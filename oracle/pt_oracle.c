@@ -338,6 +338,7 @@ static inline void sphere_record(const ora_sphere *s, int prim, float t, const r
     h->prim = prim;
 }
 /* sphere.rs:46-69 */
+static inline void ev(char c);
 static inline int sphere_trace(const ora_sphere *s, int prim, const ray_t *ray, float min_t, float max_t,
                                hit_t *h, ora_counters *cnt)
 {
@@ -348,6 +349,7 @@ static inline int sphere_trace(const ora_sphere *s, int prim, const ray_t *ray, 
     float d = b * b - a * c;
     if (cnt) cnt->sphere_tests++;
     if (d > 0.0f) {
+        ev('P');                                        /* positive discriminant: roots evaluated */
         float sol = (-b - sqrtf(d)) / a;
         if (sol < max_t && sol > min_t) {
             if (cnt) cnt->sphere_near_hits++;
@@ -478,7 +480,8 @@ static void bvh_free(bvh_node *n)
     if (!n) return;
     bvh_free(n->left); bvh_free(n->right); free(n);
 }
-/* optional per-thread event log (tools/sim_vote.py): 'S' box test, 'L' sphere test that misses, 'X' one that hits,
+/* optional per-thread event log (tools/sim_vote.py): 'S' box test, 'P' (before L/X) the sphere test has a positive discriminant,
+ * 'L' sphere test that misses, 'X' one that hits,
  * 'H' scatter, 'E' end of path */
 static __thread char *ev_buf; static __thread int ev_n, ev_cap;
 static inline void ev(char c) { if (ev_buf) { if (ev_n < ev_cap) ev_buf[ev_n] = c; ev_n++; } }

@@ -257,3 +257,63 @@ def sim_shade(lanes, w=(1, 2, 1), keep8=4, cost=COST):
                 if pos[i] < n[i] and lanes[i][pos[i]] in "HE":
                     pos[i] += 1
     return issue, useful, steps, act
+
+
+def sim_classes(lanes, weights, cost, run=("S",), keep8=4, vote_cost=10, combine=None):
+    """Generic plurality vote over the event alphabet of `lanes` (one char per step); classes in
+    `run` execute as runs (while >= keep/8 of the starters remain).  combine: dict class ->
+    (classes executed together with it, e.g. {"Z": "HE"})."""
+    pos = [0] * 64
+    n = [len(x) for x in lanes]
+    issue = 0
+    steps = {k: 0 for k in weights}
+    act = {k: 0 for k in weights}
+    while True:
+        cnt = {k: 0 for k in weights}
+        for i in range(64):
+            if pos[i] < n[i]:
+                cnt[lanes[i][pos[i]]] += 1
+        top, pick = 0, None
+        for k in weights:
+            v = cnt[k] * weights[k]
+            if v > top:
+                top, pick = v, k
+        if pick is None:
+            break
+        issue += vote_cost
+        if pick in run:
+            keep = (cnt[pick] * keep8 + 7) >> 3
+            while True:
+                c = 0
+                for i in range(64):
+                    if pos[i] < n[i] and lanes[i][pos[i]] == pick:
+                        pos[i] += 1
+                        c += 1
+                issue += cost[pick]
+                steps[pick] += 1
+                act[pick] += c
+                c = sum(1 for i in range(64) if pos[i] < n[i] and lanes[i][pos[i]] == pick)
+                if not (c >= keep and keep > 0):
+                    break
+        else:
+            c = 0
+            for i in range(64):
+                if pos[i] < n[i] and lanes[i][pos[i]] == pick:
+                    pos[i] += 1
+                    c += 1
+            issue += cost[pick]
+            steps[pick] += 1
+            act[pick] += c
+    return issue, 0, steps, act
+
+
+def report2(name, tiles, paths, **kw):
+    issue = 0
+    steps, act = {}, {}
+    for lanes in tiles:
+        i, _, s, a = sim_classes(lanes, **kw)
+        issue += i
+        for k in s:
+            steps[k] = steps.get(k, 0) + s[k]
+            act[k] = act.get(k, 0) + a[k]
+    print("%-34s issue/path %6.1f  lanes/step %s" % (name, issue / paths, " ".join("%s %.1f" % (k, act[k] / max(1, steps[k])) for k in steps)))
