@@ -303,3 +303,21 @@ def test_sample_grid_division(renderer, size, samples):
     rt = make_raytracer("simple", size[0], size[1], samples)
     renderer.bind(rt)
     assert renderer.selftest_grid(samples) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,size,samples", [("rtow", (128, 72), 12), ("simple", (200, 120), 9)])
+def test_pieces_continue_the_sum_in_order(renderer, oracle, kind, size, samples):
+    """One lane per pixel and > 32 samples: the launch is cut into (piece, tile) items that
+    different waves render and chain through the radiance buffer (ticket order + per-tile
+    release/acquire).  The per-pixel sum must still be the oracle's sequential fp32 sum."""
+    rt = make_raytracer(kind, size[0], size[1], samples)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, samples, seed=77)["radiance"]
+    renderer.set_lanes_per_pixel(1)
+    try:
+        img, rad, _ = renderer.render(rt, seed=77, radiance=True)
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert same_bits(rad, ref)
+    assert np.array_equal(img, osc.resolve(ref, samples))
