@@ -38,7 +38,8 @@ typedef enum {
     PT_ERR_HIP = -2,       /* a HIP runtime call failed                    */
     PT_ERR_NO_SCENE = -3,  /* render called before scene / camera upload   */
     PT_ERR_NO_DEVICE = -4, /* no usable gfx950 device                      */
-    PT_ERR_LIMIT = -5      /* size beyond a documented maximum             */
+    PT_ERR_LIMIT = -5,     /* size beyond a documented maximum             */
+    PT_ERR_CANCELLED = -6  /* a progress callback asked to stop            */
 } pt_status;
 
 /* Sphere {center, radius, material}: src/traceable/sphere.rs:20-24.  `material`
@@ -143,6 +144,18 @@ int pt_render_device(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sa
 int pt_resolve_device(pt_context *ctx, int32_t samples, const float *d_radiance, uint8_t *d_rgb8, void *stream);
 int pt_primary_hits_device(pt_context *ctx, int32_t samples, int32_t sample_index, int32_t *d_hit_id,
                            float *d_hit_t, void *stream);
+
+/* pt_render in `passes` launches over consecutive sample-index ranges, calling
+ * progress(user, samples_done, samples_total) on the calling thread after each one: the
+ * counterpart of Statistics::pixels_done + the reporter thread (src/raytracer.rs:108-116,
+ * src/main.rs:41-71), which count finished pixels where this counts finished samples of every
+ * pixel.  Each pass continues the per-pixel sums of the previous one in sample order, so the
+ * image equals pt_render's bit for bit whenever one lane owns a pixel (frames of >= 524,288
+ * pixels, or pt_set_lanes_per_pixel(1)); small frames differ by summation order only.  A
+ * non-zero return from the callback stops the render: PT_ERR_CANCELLED, outputs untouched. */
+typedef int (*pt_progress_fn)(void *user, int32_t samples_done, int32_t samples_total);
+int pt_render_progress(pt_context *ctx, int32_t samples, uint64_t seed, int32_t passes, pt_progress_fn progress,
+                       void *user, uint8_t *rgb8, float *radiance);
 
 /* Milliseconds the path kernel of the most recent pt_render / pt_render_device
  * took, measured with HIP events on the stream it was launched on.  Synchronises

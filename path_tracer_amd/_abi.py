@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpt_amd.so")
 
 PT_OK = 0
+PT_ERR_CANCELLED = -6
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32)   # pt_progress_fn
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 
 
@@ -56,6 +58,8 @@ SIGNATURES = {
                             C.c_void_p]),
     "pt_render_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
+    "pt_render_progress": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "pt_resolve_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_primary_hits_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_last_path_kernel_ms": (C.c_float, [C.c_void_p]),

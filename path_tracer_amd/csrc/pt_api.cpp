@@ -542,6 +542,39 @@ int pt_render(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begi
     return PT_OK;
 }
 
+int pt_render_progress(pt_context *c, int32_t samples, uint64_t seed, int32_t passes, pt_progress_fn progress, void *user,
+                       uint8_t *rgb8, float *radiance)
+{
+    int rc = check_ready(c, samples);
+    if (rc != PT_OK) return rc;
+    const int32_t total = samples * samples;
+    if (passes < 1 || passes > total) return fail(c, PT_ERR_INVALID, "passes = %d not in [1, %d]", passes, total);
+    PT_HIP(c, hipSetDevice(c->device));
+    rc = ensure_frame(c);
+    if (rc != PT_OK) return rc;
+    const size_t px = (size_t)c->frame_pixels;
+    for (int32_t k = 0; k < passes; k++) {
+        const int32_t begin = (int32_t)((int64_t)total * k / passes), end = (int32_t)((int64_t)total * (k + 1) / passes);
+        rc = pt_render_device(c, samples, seed, begin, end, k > 0, c->d_radiance, nullptr);
+        if (rc != PT_OK) return rc;
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        int32_t ctrl[2] = {0, 0};
+        PT_HIP(c, hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost));
+        if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
+        if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
+        if (progress && progress(user, end, total) != 0)
+            return fail(c, PT_ERR_CANCELLED, "cancelled by the progress callback after %d of %d samples", end, total);
+    }
+    if (rgb8) {
+        rc = pt_resolve_device(c, samples, c->d_radiance, c->d_rgb8, nullptr);
+        if (rc != PT_OK) return rc;
+        PT_HIP(c, hipMemcpyAsync(rgb8, c->d_rgb8, px * 3, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (radiance) PT_HIP(c, hipMemcpyAsync(radiance, c->d_radiance, px * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 float pt_last_path_kernel_ms(pt_context *c)
 {
     if (!c || !c->timed) return -1.0f;

@@ -90,6 +90,19 @@ class ParallelRenderer:
             return buffer, rad, ids
         return buffer
 
+    def render_progress(self, raytracer, passes, progress=None, seed=0, radiance=False):
+        """pt_render_progress: the frame in `passes` launches; ``progress(done, total)`` is called
+        after each (return a true value to cancel -> PtError with code PT_ERR_CANCELLED)."""
+        self.bind(raytracer)
+        w, h, s = raytracer.width(), raytracer.height(), raytracer.samples
+        buffer = np.zeros((h, w, 3), dtype=np.uint8)
+        rad = np.zeros((h, w, 3), dtype=np.float32) if radiance else None
+        cb = _abi.PROGRESS_FN(lambda _user, done, total: 1 if (progress and progress(done, total)) else 0)
+        _abi.check(self._ctx, _abi.lib().pt_render_progress(
+            self._ctx, s, int(seed) & (2 ** 64 - 1), int(passes), C.cast(cb, C.c_void_p), None, buffer.ctypes.data,
+            rad.ctypes.data if rad is not None else None))
+        return (buffer, rad) if radiance else buffer
+
     # -- device-resident halves (spp-sharded multi-GPU) -----------------------------
     def render_device(self, raytracer, d_radiance_ptr, seed=0, sample_range=None, accumulate=False, stream=None):
         self.bind(raytracer)

@@ -321,3 +321,24 @@ def test_pieces_continue_the_sum_in_order(renderer, oracle, kind, size, samples)
         renderer.set_lanes_per_pixel(0)
     assert same_bits(rad, ref)
     assert np.array_equal(img, osc.resolve(ref, samples))
+
+
+@pytest.mark.gpu
+def test_render_progress_reports_and_matches_render(renderer, oracle):
+    """pt_render_progress: the callback sees every pass (the reporter of main.rs:41-71), the image
+    is the one-launch image bit for bit, and a true return value cancels."""
+    import path_tracer_amd as pt
+    rt = make_raytracer("rtow", 96, 54, 6)
+    seen = []
+    renderer.set_lanes_per_pixel(1)
+    try:
+        ref_img, ref_rad, _ = renderer.render(rt, seed=11, radiance=True)
+        img, rad = renderer.render_progress(rt, 5, lambda done, total: seen.append((done, total)), seed=11, radiance=True)
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert [d for d, _ in seen] == [7, 14, 21, 28, 36] and all(t == 36 for _, t in seen)
+    assert same_bits(rad, ref_rad) and np.array_equal(img, ref_img)
+    with pytest.raises(pt.PtError) as err:
+        renderer.render_progress(rt, 4, lambda done, total: done >= 18, seed=11)
+    assert err.value.code == -6                                                   # PT_ERR_CANCELLED
+    assert np.array_equal(renderer.render(rt, seed=11), renderer.render(rt, seed=11))   # context still usable
