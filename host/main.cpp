@@ -1,7 +1,7 @@
 // main.cpp -- plays the role of the reference's src/main.rs (:73-122) on top of the C ABI:
 // hard-coded camera (main.rs:80-87), scene choice (main.rs:91-92), render, write the image.
-// The reference writes output.png through the `image` crate (main.rs:118-121); PNG encoding is
-// outside the hot path, so this harness writes a binary PPM.
+// Progress lines like the reporter thread's (main.rs:41-71); output.png like main.rs:118-121
+// (uncompressed PNG, written by pt::write_png).
 //   pt_main [random|rtow|simple <earthmap.ppm>] [width height samples]
 #include <chrono>
 #include <cstdio>
@@ -45,15 +45,18 @@ int main(int argc, char **argv)
                     std::chrono::duration<double>(t1 - t0).count());               // scene/mod.rs:51-59
         pt::ParallelRenderer renderer(0);
         std::vector<uint8_t> buffer(raytracer.pixel_count() * 3);                   // main.rs:98
-        renderer.render(raytracer, buffer.data(), 20260711ull);
+        const int passes = samples * samples >= 64 ? 8 : 1;
+        renderer.render_progress(raytracer, buffer.data(), 20260711ull, passes, [&](int done, int total) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            std::printf("Progress: %.1f%%, %.1fs elapsed, ~%.1fs left\n", 100.0 * done / total, el, el * (total - done) / done);
+            return false;
+        });
         const auto t2 = std::chrono::steady_clock::now();
         const double paths = (double)raytracer.pixel_count() * samples * samples;
-        std::printf("%d x %d @ %d spp: %.3fs elapsed (path kernel %.1f ms, %.0f Mpaths/s)\n", width, height, samples * samples,
-                    std::chrono::duration<double>(t2 - t1).count(), renderer.last_path_kernel_ms(),
-                    paths / (renderer.last_path_kernel_ms() * 1e-3) / 1e6);
-        std::ofstream out("output.ppm", std::ios::binary);
-        out << "P6\n" << width << " " << height << "\n255\n";
-        out.write((const char *)buffer.data(), (std::streamsize)buffer.size());
+        const double render_s = std::chrono::duration<double>(t2 - t1).count();
+        std::printf("%d x %d @ %d spp: %.3fs elapsed incl. upload (%.0f Mpaths/s)\n", width, height, samples * samples, render_s,
+                    paths / render_s / 1e6);
+        if (!pt::write_png("output.png", buffer.data(), width, height)) throw std::runtime_error("cannot write output.png");
         return 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -11,6 +11,7 @@
 // ABI itself only returns status codes.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -181,7 +182,70 @@ public:
         check(pt_set_camera(ctx_, &rt.camera.pod));
         check(pt_render(ctx_, rt.samples, seed, 0, rt.samples * rt.samples, buffer, radiance, hit_id));
     }
+    // the same frame in `passes` launches with a progress report after each: Statistics::pixels_done
+    // + the reporter thread of main.rs:41-71 (progress(done, total) returns true to cancel)
+    template <typename F>
+    void render_progress(const Raytracer &rt, uint8_t *buffer, uint64_t seed, int passes, F progress)
+    {
+        check(pt_upload_scene(ctx_, rt.spheres.data(), (int32_t)rt.spheres.size(), rt.materials.data(), (int32_t)rt.materials.size(),
+                              rt.textures.data(), (int32_t)rt.textures.size(), rt.nodes.data(), (int32_t)rt.nodes.size()));
+        check(pt_set_camera(ctx_, &rt.camera.pod));
+        auto thunk = [](void *user, int32_t done, int32_t total) -> int { return (*(F *)user)(done, total) ? 1 : 0; };
+        check(pt_render_progress(ctx_, rt.samples, seed, passes, thunk, &progress, buffer, nullptr));
+    }
     float last_path_kernel_ms() { return pt_last_path_kernel_ms(ctx_); }
 };
+
+// Minimal PNG writer (8-bit RGB, zlib "stored" blocks: no compression) for the output.png of
+// main.rs:118-121; the reference encodes through the `png` crate, any decoder reads both.
+inline bool write_png(const char *path, const uint8_t *rgb8, int width, int height)
+{
+    auto crc32 = [](const std::vector<uint8_t> &d, size_t from) {
+        uint32_t c = 0xffffffffu;
+        for (size_t i = from; i < d.size(); i++) {
+            c ^= d[i];
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        }
+        return c ^ 0xffffffffu;
+    };
+    auto be32 = [](std::vector<uint8_t> &d, uint32_t v) { for (int s = 24; s >= 0; s -= 8) d.push_back((uint8_t)(v >> s)); };
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    auto chunk = [&](const char *type, const std::vector<uint8_t> &body) {
+        be32(out, (uint32_t)body.size());
+        const size_t from = out.size();
+        out.insert(out.end(), type, type + 4);
+        out.insert(out.end(), body.begin(), body.end());
+        be32(out, crc32(out, from));
+    };
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)width); be32(ihdr, (uint32_t)height);
+    ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});                       // 8 bit, colour type 2 (RGB), no interlace
+    chunk("IHDR", ihdr);
+    std::vector<uint8_t> raw;                                        // filter byte 0 + row
+    raw.reserve((size_t)height * ((size_t)width * 3 + 1));
+    for (int y = 0; y < height; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb8 + (size_t)y * width * 3, rgb8 + (size_t)(y + 1) * width * 3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};                           // zlib header, then stored deflate blocks
+    uint32_t a = 1, b = 0;                                           // Adler-32 of raw
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        const size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 255)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 255)); z.push_back((uint8_t)((~n >> 8) & 255));
+        for (size_t i = pos; i < pos + n; i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)pos, raw.begin() + (std::ptrdiff_t)(pos + n));
+        pos += n;
+        if (n == 0) break;
+    }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    return std::fclose(f) == 0 && ok;
+}
 
 }  // namespace pt

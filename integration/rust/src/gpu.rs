@@ -34,6 +34,9 @@ extern "C" {
                             accumulate: i32, d_radiance: *mut f32, stream: *mut c_void) -> c_int;
     pub fn pt_resolve_device(ctx: *mut pt_context, samples: i32, d_radiance: *const f32, d_rgb8: *mut u8,
                              stream: *mut c_void) -> c_int;
+    pub fn pt_render_progress(ctx: *mut pt_context, samples: i32, seed: u64, passes: i32,
+                              progress: Option<extern "C" fn(*mut c_void, i32, i32) -> c_int>, user: *mut c_void,
+                              rgb8: *mut u8, radiance: *mut f32) -> c_int;
     // optional start-up checks (include/pt_amd.h): both must report 0 mismatches
     pub fn pt_selftest_unary(ctx: *mut pt_context, func: i32, mismatches: *mut u64) -> c_int;
     pub fn pt_selftest_grid(ctx: *mut pt_context, samples: i32, mismatches: *mut u64) -> c_int;

@@ -182,3 +182,22 @@ def test_med3_slab_identity():
     e = med3(med3(med3(E, x0, x1), y0, y1), z0, z1)
     f = med3(med3(med3(Fc, x0, x1), y0, y1), z0, z1)
     assert np.array_equal(true, e < f)
+
+
+def test_cpp_host_png_writer_roundtrip(tmp_path):
+    """host/pt_host.hpp write_png (the output.png of main.rs:118-121): a decoder reads back the
+    exact pixels, including a frame wider than one 64 KiB stored block."""
+    import subprocess
+    from PIL import Image
+    src = tmp_path / "png.cpp"
+    src.write_text('#include "%s/host/pt_host.hpp"\n'
+                   'int main(int c, char **v) { int w = 301, h = 97; std::vector<uint8_t> px((size_t)w * h * 3);\n'
+                   '  for (size_t i = 0; i < px.size(); i++) px[i] = (uint8_t)((i * 2654435761u) >> 13);\n'
+                   '  return c > 1 && pt::write_png(v[1], px.data(), w, h) ? 0 : 1; }\n' % ROOT)
+    exe, out = tmp_path / "png", tmp_path / "o.png"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), str(src)], check=True)
+    subprocess.run([str(exe), str(out)], check=True)
+    img = np.asarray(Image.open(out).convert("RGB"))
+    i = np.arange(301 * 97 * 3, dtype=np.uint64)
+    want = (((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(13)).astype(np.uint8).reshape(97, 301, 3)
+    assert img.shape == (97, 301, 3) and np.array_equal(img, want)
