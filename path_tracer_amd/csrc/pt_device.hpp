@@ -381,43 +381,46 @@ PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f
     // Sphere::record (sphere.rs:37-42)
     const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
     const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));
-    if (mb.x == 0) {                                                             // lambertian.rs:32-45
-        f3 target = (p + n) + random_in_unit_sphere(rng);
+    // The three Material::scatter bodies share their expensive pieces, so those are written once
+    // and run once per step for the lanes of every material that needs them (each lane still
+    // executes exactly its material's operations, in its material's order):
+    //   reflect(d, n)            metal.rs:23, dielectric.rs:32
+    //   random_in_unit_sphere    lambertian.rs:33, metal.rs:26 (drawn only if the ray is not absorbed)
+    //   Ray::new's normalisation ray.rs:19-24
+    const int kind = mb.x;
+    const f3 reflected = reflect(ray.d, n);                                      // unused by Lambertian lanes
+    bool alive = true;
+    if (kind == 1) alive = dot(reflected, n) > 0.0f;                             // metal.rs:25, else None (:29-31)
+    f3 unit = fill(0.0f);
+    if (kind == 0 || (kind == 1 && alive)) unit = random_in_unit_sphere(rng);
+    f3 nd;
+    if (kind == 0) {                                                             // lambertian.rs:32-45
+        f3 target = (p + n) + unit;
         att = (mb.y >= 0) ? sphere_uv_color(sc, mb.y, n) : mk(ma.x, ma.y, ma.z);
-        out.o = p; out.d = normalized(target - p);                               // ray.rs:19-24
-        return true;
-    }
-    if (mb.x == 1) {                                                             // metal.rs:22-32
-        f3 reflected = reflect(ray.d, n);
-        if (dot(reflected, n) > 0.0f) {
-            f3 fuzz = random_in_unit_sphere(rng) * ma.w;
-            att = mk(ma.x, ma.y, ma.z);
-            out.o = p; out.d = normalized(reflected + fuzz);
-            return true;
-        }
-        return false;
-    }
-    {                                                                            // dielectric.rs:20-50
+        nd = target - p;
+    } else if (kind == 1) {                                                      // metal.rs:22-32
+        f3 fuzz = unit * ma.w;
+        att = mk(ma.x, ma.y, ma.z);
+        nd = reflected + fuzz;
+    } else {                                                                     // dielectric.rs:20-50
         const float ref_idx = ma.w;
         const f3 dir = ray.d;
         const float dt = dot(dir, n);
         f3 outward; float ni_over_nt, cosine;
         if (dt > 0.0f) { cosine = ref_idx * dt; outward = neg(n); ni_over_nt = ref_idx; }
         else { cosine = -dt; outward = n; ni_over_nt = p_rcp(ref_idx); }
-        f3 reflected = reflect(dir, n);
         f3 refracted;
         att = fill(1.0f);
-        f3 nd = reflected;
+        nd = reflected;
         if (refract(dir, outward, ni_over_nt, refracted)) {
             float prob = schlick(cosine, ref_idx);
             float r = rng_f32(rng);
             nd = (r < prob) ? reflected : refracted;
         }
-        out.o = p; out.d = normalized(nd);
-        return true;
     }
+    out.o = p; out.d = normalized(nd);                                           // ray.rs:19-24 (discarded when absorbed)
+    return alive;
 }
-
 PTD f3 sky(const Ray &ray, f3 att)                                               // raytracer.rs:67-70
 {
     float t = 0.5f * (ray.d.y + 1.0f);
