@@ -342,3 +342,62 @@ def test_render_progress_reports_and_matches_render(renderer, oracle):
         renderer.render_progress(rt, 4, lambda done, total: done >= 18, seed=11)
     assert err.value.code == -6                                                   # PT_ERR_CANCELLED
     assert np.array_equal(renderer.render(rt, seed=11), renderer.render(rt, seed=11))   # context still usable
+
+
+def _fuzz_case(k):
+    """Seeded random scene + camera: sphere counts 1..80, overlapping / nested / huge / tiny spheres,
+    all three materials (fuzz 0 and 1, ref_idx below and above 1, textured Lambertian), cameras
+    inside spheres, axis-aligned views, extreme fields of view."""
+    import path_tracer_amd as pt
+    rnd = np.random.default_rng(1000 + k)
+    scene = pt.Scene.new()
+    n = int(rnd.choice([1, 2, 3, 7, 20, 45, 80]))
+    tex = pt.PictureTexture.earthmap() if k % 3 == 0 else None
+    for i in range(n):
+        c = rnd.uniform(-4, 4, 3)
+        r = float(rnd.choice([0.05, 0.3, 0.8, 2.5, 40.0], p=[0.2, 0.4, 0.25, 0.1, 0.05]))
+        if i == 0 and k % 4 == 0:
+            c, r = np.array([0.0, -500.0, 0.0]), 500.0
+        m = rnd.integers(0, 4)
+        if m == 0:
+            mat = pt.Lambertian.new_solid(tuple(rnd.uniform(0, 1, 3)))
+        elif m == 1 and tex is not None:
+            mat = pt.Lambertian.new(tex)
+        elif m <= 2:
+            mat = pt.Metal.new(tuple(rnd.uniform(0.3, 1, 3)), float(rnd.choice([0.0, 0.2, 1.0])))
+        else:
+            mat = pt.Dielectric.new(float(rnd.choice([1.5, 0.7, 1.0, 2.4])))
+        scene.add(pt.Sphere.new(tuple(float(x) for x in c), r, mat))
+    eye = rnd.uniform(-6, 6, 3)
+    target = rnd.uniform(-1, 1, 3)
+    if k % 5 == 0:                                        # axis-aligned view: zero direction components
+        eye, target = np.array([0.0, 0.0, 6.0]), np.array([0.0, 0.0, 0.0])
+    fov = float(rnd.choice([1.0, 20.0, 60.0, 120.0, 170.0]))
+    w, h = [(33, 17), (64, 36), (80, 45), (24, 64)][k % 4]
+    cam = pt.Camera.new(tuple(map(float, eye)), tuple(map(float, target)), (0.0, 1.0, 0.0), fov, w, h)
+    samples = int(rnd.choice([2, 3, 5, 7]))
+    return pt.Raytracer.new(cam, scene, samples), samples
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(24))
+def test_fuzz_scenes_bit_exact(renderer, oracle, k):
+    """Random scenes and cameras: radiance sums and primary hit ids equal the oracle's bit for bit,
+    with one lane per pixel (sequential sums, pieces when samples^2 > 32) and with the automatic
+    lanes-per-pixel split (chunked sums)."""
+    rt, samples = _fuzz_case(k)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, samples, seed=k, hit_ids=True)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        img, rad, ids = renderer.render(rt, seed=k, radiance=True, hit_ids=True)
+    finally:
+        renderer.set_lanes_per_pixel(0)
+    assert np.array_equal(ids, ref["hit_id"])
+    assert same_bits(rad, ref["radiance"])
+    assert np.array_equal(img, osc.resolve(ref["radiance"], samples))
+    renderer.bind(rt)
+    lanes = renderer.lanes_per_pixel(samples, 0, samples * samples)
+    chunk = -(-samples * samples // lanes)
+    _, rad2, _ = renderer.render(rt, seed=k, radiance=True)
+    assert same_bits(rad2, osc.render(rt.camera.pod, samples, seed=k, chunk=chunk)["radiance"])
