@@ -39,6 +39,6 @@ def init_process_group(backend, device=None):
 def reduce_radiance(accum, dist, root=0):
     """Sum the per-rank radiance buffers into `root`'s (W*H*3 fp32: 24.9 MB at 1080p).
     Only the root needs the sum, so this is a reduce, not an all-reduce."""
-    if dist is not None and dist.get_world_size() > 1:
+    if dist is not None:
         dist.reduce(accum, dst=root, op=dist.ReduceOp.SUM)
     return accum
