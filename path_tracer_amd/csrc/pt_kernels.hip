@@ -214,6 +214,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         new_path = false; new_walk = false;
         PT_TIME(5);
 
+        // walking waves issue ahead of shading ones (short dependent steps first: -1.5 %)
+        __builtin_amdgcn_s_setprio(1);
         // every ray of the wave REGULAR (pt_device.hpp)?  Re-evaluated once per SHADE step; a lane
         // whose irregular walk is over keeps the wave on the general slab test until its next walk
         const bool all_regular = __ballot(!regular) == 0ull;
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         }
         if (done) break;
 
+        __builtin_amdgcn_s_setprio(0);
         // SHADE: the lanes whose walk has ended.  A hit scatters (one iteration of
         // `for _ in 0..MAX_TRACES`, raytracer.rs:52-61) and usually starts the next walk; a miss,
         // an absorbed path or the bounce cap ends the path in the same step.
