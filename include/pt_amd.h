@@ -138,7 +138,11 @@ int pt_render(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_be
  * hipStream_t; NULL = the context's own stream).
  *   pt_render_device : d_radiance[W*H*3] = (accumulate ? old : 0) + sum over the range
  *   pt_resolve_device: d_rgb8[W*H*3] from d_radiance (raytracer.rs:92-93,119-121)
- *   pt_primary_hits_device: d_hit_id[W*H] (and optional d_hit_t[W*H]) for sample index s */
+ *   pt_primary_hits_device: d_hit_id[W*H] (and optional d_hit_t[W*H]) for sample index s
+ * The launches of one context share its work-distribution scratch: issue them on ONE stream
+ * at a time (back-to-back launches on the same stream are ordered and fine; two streams at
+ * once race).  A dependency wait that gives up inside the path kernel (never observed) is
+ * reported by the next pt_render / pt_render_progress as PT_ERR_HIP, not by these calls. */
 int pt_render_device(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
                      int32_t sample_end, int32_t accumulate, float *d_radiance, void *stream);
 int pt_resolve_device(pt_context *ctx, int32_t samples, const float *d_radiance, uint8_t *d_rgb8, void *stream);
