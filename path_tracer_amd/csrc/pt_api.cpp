@@ -135,7 +135,11 @@ int pick_lanes(const pt_context *c, int32_t count)
     if (lanes <= 0) {
         const int64_t px = (int64_t)c->camera.width * c->camera.height;
         lanes = 1;
-        while (lanes < 64 && px * lanes < kFullChipLanes) lanes *= 2;
+        // a frame that fills the chip on its own keeps one lane per pixel (sequential sums, the
+        // launch is balanced by pieces); a smaller one is spread until it covers the wave slots
+        // about three times over, so that the last round of waves is a small part of the launch
+        if (px < kFullChipLanes)
+            while (lanes < 64 && px * lanes < 3 * kFullChipLanes) lanes *= 2;
     }
     while (lanes > 1 && lanes > count) lanes /= 2;   // never more lanes than samples
     return lanes;
