@@ -142,7 +142,8 @@ int pt_render(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_be
  * The launches of one context share its work-distribution scratch: issue them on ONE stream
  * at a time (back-to-back launches on the same stream are ordered and fine; two streams at
  * once race).  A dependency wait that gives up inside the path kernel (never observed) is
- * reported by the next pt_render / pt_render_progress as PT_ERR_HIP, not by these calls. */
+ * reported by pt_last_path_kernel_ms (-2) and by pt_render / pt_render_progress (PT_ERR_HIP),
+ * not by these asynchronous calls. */
 int pt_render_device(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
                      int32_t sample_end, int32_t accumulate, float *d_radiance, void *stream);
 int pt_resolve_device(pt_context *ctx, int32_t samples, const float *d_radiance, uint8_t *d_rgb8, void *stream);
@@ -163,7 +164,8 @@ int pt_render_progress(pt_context *ctx, int32_t samples, uint64_t seed, int32_t 
 
 /* Milliseconds the path kernel of the most recent pt_render / pt_render_device
  * took, measured with HIP events on the stream it was launched on.  Synchronises
- * that stream.  Negative if no render has run. */
+ * that stream.  -1 if no render has run; -2 if that launch reported an error from inside the
+ * kernel (pt_last_error says which) -- the way to check a pt_render_device launch. */
 float pt_last_path_kernel_ms(pt_context *ctx);
 
 /* How a pixel's samples are spread over GPU lanes.  0 (default) = automatic:

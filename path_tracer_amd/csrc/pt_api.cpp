@@ -586,6 +586,13 @@ float pt_last_path_kernel_ms(pt_context *c)
     if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0f;
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0f;
+    // the launch is complete: its error word can be read (see pt_render)
+    int32_t ctrl[2] = {0, 0};
+    if (c->d_sched && hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost) == hipSuccess && ctrl[1] != 0) {
+        (void)fail(c, PT_ERR_HIP, ctrl[1] == 2 ? "path kernel: dynamic LDS does not start at address 0"
+                                               : "path kernel: a piece gave up waiting for its predecessor");
+        return -2.0f;
+    }
     return ms;
 }
 

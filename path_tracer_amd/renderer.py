@@ -125,7 +125,10 @@ class ParallelRenderer:
             C.c_void_p(d_hit_t_ptr) if d_hit_t_ptr else None, C.c_void_p(stream) if stream else None))
 
     def last_path_kernel_ms(self):
-        return float(_abi.lib().pt_last_path_kernel_ms(self._ctx))
+        ms = float(_abi.lib().pt_last_path_kernel_ms(self._ctx))
+        if ms == -2.0:
+            _abi.check(self._ctx, -2)        # PT_ERR_HIP with the kernel's message
+        return ms
 
     def selftest_grid(self, samples):
         """pt_selftest_grid for the bound camera: sample-grid coordinates that differ from the
