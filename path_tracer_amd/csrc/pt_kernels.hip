@@ -80,6 +80,78 @@ constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
 #define PT_MIN_WAVES 8   // waves per SIMD the register allocator must leave room for (64 VGPRs)
 #endif
 
+// SPLIT run for REGULAR rays (pt_device.hpp split_step<true>, one AABB::intersect per iteration),
+// hand-scheduled.  Entered by the lanes standing on a Split; a lane leaves (exec shrinks) when
+// its code stops being a Split, and the run ends for all once fewer than `keep` remain; exec is
+// restored on exit.  21 (ALL_IN_LDS) / 22 VALU + 3 / 8 SALU + one branch per node, against the
+// compiler's 23 + 7 for the same C++ loop: the scalar unit is shared by the CU's four SIMDs, so
+// loop control costs as much as arithmetic (tools/ubench/salu_rate.hip).  -5 %.
+//   n1 (bmax, next code) comes through the L1; n0 (bmin, skip code) from LDS -- for the lanes
+//   inside the staged prefix when the tree is larger than it, through the L1 for the others,
+//   that load skipped when no lane needs it.
+// The arithmetic is split_step<true>'s, instruction for instruction; v48-v57 are scratch.
+template <bool ALL_IN_LDS>
+__device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, const f3 inv, const float closest, const Scene &sc,
+                                                     const int n_split_end, const int keep)
+{
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const uint64_t b1 = (uint64_t)(uintptr_t)sc.n1, b0 = (uint64_t)(uintptr_t)sc.n0;
+    const v4u rs1 = {(uint32_t)b1, (uint32_t)(b1 >> 32) & 0xffffu, (uint32_t)(sc.n_nodes * 16), 0x00020000u};
+    const v4u rs0 = {(uint32_t)b0, (uint32_t)(b0 >> 32) & 0xffffu, (uint32_t)(sc.n_nodes * 16), 0x00020000u};
+    uint64_t save, cur; int cnt;
+#define PT_RUN_TEST \
+    "v_sub_f32 v48, v48, %[ox]\n v_sub_f32 v49, v49, %[oy]\n v_sub_f32 v50, v50, %[oz]\n" \
+    "v_mul_f32 v48, %[ix], v48\n v_mul_f32 v49, %[iy], v49\n v_mul_f32 v50, %[iz], v50\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    "v_sub_f32 v52, v52, %[ox]\n v_sub_f32 v53, v53, %[oy]\n v_sub_f32 v54, v54, %[oz]\n" \
+    "v_mul_f32 v52, %[ix], v52\n v_mul_f32 v53, %[iy], v53\n v_mul_f32 v54, %[iz], v54\n" \
+    "v_med3_f32 v56, v48, v52, %[tmin]\n v_med3_f32 v57, %[t], v48, v52\n" \
+    "v_med3_f32 v56, v56, v49, v53\n v_med3_f32 v57, v57, v49, v53\n" \
+    "v_med3_f32 v56, v56, v50, v54\n v_med3_f32 v57, v57, v50, v54\n" \
+    "v_cmp_lt_f32 vcc, v56, v57\n s_nop 1\n" \
+    "v_cndmask_b32 %[code], v51, v55, vcc\n" \
+    "v_cmp_gt_u32 vcc, %[nspl], %[code]\n" \
+    "s_bcnt1_i32_b64 %[cnt], vcc\n s_cmp_ge_i32 %[cnt], %[keep]\n s_cselect_b64 exec, vcc, 0\n"
+    if (ALL_IN_LDS) {
+        asm volatile("s_mov_b64 %[save], exec\n"
+                     ".LPTRUN%=:\n"
+                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
+                     "ds_read_b128 v[48:51], %[code]\n"
+                     "s_waitcnt lgkmcnt(0)\n"
+                     PT_RUN_TEST
+                     "s_cbranch_execnz .LPTRUN%=\n"
+                     "s_mov_b64 exec, %[save]\n"
+                     : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
+                     : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
+                       [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep)
+                     : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+    } else {
+        asm volatile("s_mov_b64 %[save], exec\n"
+                     ".LPTRUN%=:\n"
+                     "v_cmp_gt_u32 vcc, %[lim], %[code]\n"
+                     "s_mov_b64 %[cur], exec\n"
+                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
+                     "s_andn2_b64 exec, %[cur], vcc\n"
+                     "s_cbranch_execz .LPTNODEEP%=\n"
+                     "buffer_load_dwordx4 v[48:51], %[code], %[rs0], 0 offen\n"
+                     ".LPTNODEEP%=:\n"
+                     "s_and_b64 exec, %[cur], vcc\n"
+                     "ds_read_b128 v[48:51], %[code]\n"
+                     "s_mov_b64 exec, %[cur]\n"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+                     PT_RUN_TEST
+                     "s_cbranch_execnz .LPTRUN%=\n"
+                     "s_mov_b64 exec, %[save]\n"
+                     : [code] "+v"(code), [save] "=&s"(save), [cur] "=&s"(cur), [cnt] "=&s"(cnt)
+                     : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
+                       [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
+                       [lim] "s"(sc.lds_nodes << 4)
+                     : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+    }
+#undef PT_RUN_TEST
+    return code;
+}
+
 template <bool ALL_IN_LDS>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
                                                                     float *radiance)
@@ -232,15 +304,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
                 if ((uint32_t)code < (uint32_t)n_nodes) {
                     if (all_regular) {
-                        for (;;) {
-                            PT_STAT(0, lanes(true));
-                            float4 n0, n1;
-                            fetch(code, n0, n1, true);
-                            code = split_step<true>(n0, n1, ray.o, inv, h.t);
-                            const bool at = (uint32_t)code < (uint32_t)n_nodes;
-                            const bool few = lanes(at) < keep;
-                            if ((int)!at | (int)few) break;
-                        }
+                        code = split_run_regular<ALL_IN_LDS>(code, ray.o, inv, h.t, sc, n_nodes, keep);
                     } else {
                         for (;;) {
                             PT_STAT(0, lanes(true));
