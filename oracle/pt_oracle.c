@@ -480,7 +480,7 @@ static void bvh_free(bvh_node *n)
     if (!n) return;
     bvh_free(n->left); bvh_free(n->right); free(n);
 }
-/* optional per-thread event log (tools/sim_vote.py): 'S' box test, 'P' (before L/X) the sphere test has a positive discriminant,
+/* optional per-thread event log (tests/experiments/sim_vote.py): 'S' box test, 'P' (before L/X) the sphere test has a positive discriminant,
  * 'L' sphere test that misses, 'X' one that hits,
  * 'H' scatter, 'E' end of path */
 static __thread char *ev_buf; static __thread int ev_n, ev_cap;

@@ -1,8 +1,8 @@
 /* Design experiment (not product code, not test code): how many box / sphere tests per path
  * would other BVH builds and child orders need, and how often would the closest hit differ
  * from the reference order's?  Reuses the oracle's static functions by inclusion.
- *   gcc -O2 -ffp-contract=off -o /tmp/exp_bvh tools/exp/exp_bvh.c -lm -lpthread */
-#include "../../oracle/pt_oracle.c"
+ *   gcc -O2 -ffp-contract=off -o /tmp/exp_bvh tests/experiments/exp_bvh.c -lm -lpthread */
+#include "../../oracle/pt_oracle.c"   /* test-side experiment: the only place besides tests/ proper that may */
 #include <stdio.h>
 
 typedef struct xnode { int leaf, prim, axis; v3 bmin, bmax; struct xnode *l, *r; } xnode;

@@ -3,7 +3,7 @@
 Takes the per-path event strings of the oracle (ora_trace_path_events: S box test, L sphere
 test, H scatter, E end of path) for the 64 pixels of some 8x8 tiles and replays them through
 scheduling policies, counting issue cost (wave-steps x instructions per step) against the
-useful lane-steps.  Uses oracle/ -> tools-only, never imported by the package."""
+useful lane-steps.  Uses oracle/, hence it lives under tests/ (the only tree allowed to); never imported by the package."""
 import ctypes as C
 import os
 import random
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib  # noqa: E402
