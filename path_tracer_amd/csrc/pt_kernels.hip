@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     };
     auto lanes = [&](bool p) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(p))); };
 
-    // SPLIT and LEAF steps go straight back to the vote; HIT and END fall through to
+    // SPLIT and LEAF steps go straight back to the vote; SHADE falls through to
     // the shared tails: new_path -> the next sample's camera ray (or DONE),
     // new_walk -> Scene::trace prologue (scene/mod.rs:24-34), standing on the root.
 #ifdef PT_STATS

@@ -9,7 +9,7 @@ struct RenderParams {
     int32_t lanes;        // lanes per pixel: power of two in [1, 64]
     int32_t accumulate;   // continue the sum already in the radiance buffer
     float inv_s1, inv_w, inv_h;   // 1/(S-1), 1/W, 1/H: correctly rounded fp32 reciprocals (host), for div_by
-    unsigned long long *stats;   // PT_STATS builds only: 8 counters {steps, active lanes} x {SPLIT, LEAF, HIT, END}
+    unsigned long long *stats;   // PT_STATS builds only: {steps, active lanes} x {SPLIT, LEAF, SHADE:hit, SHADE:end}, then 6 cycle buckets
 };
 
 // Work distribution of the path kernel: one wave per (piece, tile) item, items handed out
