@@ -304,7 +304,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
                 if ((uint32_t)code < (uint32_t)n_nodes) {
                     if (all_regular) {
+#ifndef PT_STATS
                         code = split_run_regular<ALL_IN_LDS>(code, ray.o, inv, h.t, sc, n_nodes, keep);
+#else   // the same run in C++, with its step counters
+                        for (;;) {
+                            PT_STAT(0, lanes(true));
+                            float4 n0, n1;
+                            fetch(code, n0, n1, true);
+                            code = split_step<true>(n0, n1, ray.o, inv, h.t);
+                            const bool at = (uint32_t)code < (uint32_t)n_nodes;
+                            const bool few = lanes(at) < keep;
+                            if ((int)!at | (int)few) break;
+                        }
+#endif
                     } else {
                         for (;;) {
                             PT_STAT(0, lanes(true));
