@@ -35,9 +35,7 @@ struct pt_context {
 
     // device scene
     float4 *d_nodes = nullptr;
-    float4 *d_spheres = nullptr;
-    float4 *d_shade_a = nullptr;
-    int2 *d_shade_b = nullptr;
+    float4 *d_prims = nullptr;
     ptd::Texture *d_textures = nullptr;
     std::vector<uint8_t *> d_texels;
     ptd::Scene scene{};
@@ -81,14 +79,10 @@ int fail(pt_context *ctx, int code, const char *fmt, ...)
 void free_scene(pt_context *c)
 {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
-    if (c->d_spheres) (void)hipFree(c->d_spheres);
-    if (c->d_shade_a) (void)hipFree(c->d_shade_a);
-    if (c->d_shade_b) (void)hipFree(c->d_shade_b);
+    if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_textures) (void)hipFree(c->d_textures);
     for (uint8_t *p : c->d_texels) (void)hipFree(p);
-    c->d_nodes = c->d_spheres = nullptr;
-    c->d_shade_a = nullptr;
-    c->d_shade_b = nullptr;
+    c->d_nodes = c->d_prims = nullptr;
     c->d_textures = nullptr;
     c->d_texels.clear();
     c->have_scene = false;
@@ -269,15 +263,12 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     // top of the tree -- visited by every ray -- is the prefix the path kernel keeps
     // in LDS; the walk order is unchanged, it follows the explicit next/skip codes.
     std::vector<int32_t> slot, order;
-    std::vector<float4> h_nodes, h_spheres, h_shade_a;
-    std::vector<int2> h_shade_b;
+    std::vector<float4> h_nodes, h_prims;
     try {
         slot.resize((size_t)n_nodes);
         order.reserve((size_t)n_nodes);
         h_nodes.resize(2 * (size_t)n_nodes);
-        h_spheres.resize((size_t)n_spheres);
-        h_shade_a.resize((size_t)n_spheres);
-        h_shade_b.resize((size_t)n_spheres);
+        h_prims.resize(2 * (size_t)n_spheres);
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
@@ -315,22 +306,21 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     }
     for (int32_t i = 0; i < n_spheres; i++) {
         const pt_material &m = materials[spheres[i].material];
-        h_spheres[i] = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, spheres[i].radius);
-        h_shade_a[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
-        h_shade_b[i] = make_int2(m.kind, m.kind == PT_LAMBERTIAN ? m.texture : -1);
+        const int32_t tex = m.kind == PT_LAMBERTIAN ? m.texture : -1;
+        const int32_t tag = m.kind | ((tex + 1) << 2);
+        float4 a = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, 0.0f);
+        std::memcpy(&a.w, &tag, 4);
+        h_prims[2 * (size_t)i] = a;
+        h_prims[2 * (size_t)i + 1] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
     }
 
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     PT_HIP(c, hipMalloc((void **)&c->d_nodes, h_nodes.size() * sizeof(float4)));
-    PT_HIP(c, hipMalloc((void **)&c->d_spheres, h_spheres.size() * sizeof(float4)));
-    PT_HIP(c, hipMalloc((void **)&c->d_shade_a, h_shade_a.size() * sizeof(float4)));
-    PT_HIP(c, hipMalloc((void **)&c->d_shade_b, h_shade_b.size() * sizeof(int2)));
+    PT_HIP(c, hipMalloc((void **)&c->d_prims, h_prims.size() * sizeof(float4)));
     PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemcpy(c->d_spheres, h_spheres.data(), h_spheres.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemcpy(c->d_shade_a, h_shade_a.data(), h_shade_a.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemcpy(c->d_shade_b, h_shade_b.data(), h_shade_b.size() * sizeof(int2), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_prims, h_prims.data(), h_prims.size() * sizeof(float4), hipMemcpyHostToDevice));
     if (n_textures > 0) {
         std::vector<ptd::Texture> h_tex((size_t)n_textures);
         for (int32_t i = 0; i < n_textures; i++) {
@@ -348,9 +338,7 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     }
     c->scene.n0 = c->d_nodes;
     c->scene.n1 = c->d_nodes + n_nodes;
-    c->scene.spheres = c->d_spheres;
-    c->scene.shade_a = c->d_shade_a;
-    c->scene.shade_b = c->d_shade_b;
+    c->scene.prims = c->d_prims;
     c->scene.textures = c->d_textures;
     c->scene.n_nodes = n_nodes;
     c->scene.n_spheres = n_spheres;

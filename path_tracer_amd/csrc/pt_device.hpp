@@ -183,9 +183,10 @@ PTD float p_asinf(float y)
 struct Texture { const uint8_t *rgb8; int32_t width, height; };
 struct Scene {
     const float4 *n0, *n1;   // one float4 each per node (layout below)
-    const float4 *spheres;   // per primitive: (cx, cy, cz, radius), Scene::add order
-    const float4 *shade_a;   // per primitive: its material's (albedo r, g, b, param)
-    const int2 *shade_b;     // per primitive: its material's (kind, texture index or -1)
+    // per primitive (Scene::add order), 32 bytes = one half cache line for a hit's two loads:
+    //   prims[2 i]     = (cx, cy, cz, bits(kind | (texture index + 1) << 2))
+    //   prims[2 i + 1] = its material's (albedo r, g, b, param)
+    const float4 *prims;
     const Texture *textures;
     int32_t n_nodes, n_spheres;
     int32_t root_code;       // node code of the root
@@ -375,9 +376,9 @@ PTD Hit scene_trace(const Scene &sc, const Ray &ray)
 // returns false when the path is absorbed (metal.rs:29-31)
 PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
 {
-    const float4 sp = sc.spheres[h.prim];
-    const float4 ma = sc.shade_a[h.prim];
-    const int2 mb = sc.shade_b[h.prim];
+    const float4 sp = sc.prims[2 * h.prim];
+    const float4 ma = sc.prims[2 * h.prim + 1];
+    const int2 mb = make_int2(__float_as_int(sp.w) & 3, (__float_as_int(sp.w) >> 2) - 1);   // (kind, texture or -1)
     // Sphere::record (sphere.rs:37-42)
     const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
     const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));
