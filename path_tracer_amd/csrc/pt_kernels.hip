@@ -47,7 +47,7 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 // other inside one iteration.  Each lane still executes exactly the reference's
 // operation sequence for its pixel, so results do not depend on the vote.
 #ifndef PT_SPLIT_KEEP
-#define PT_SPLIT_KEEP 4   // a SPLIT run goes on while at least KEEP/8 of the lanes it started with are still at a Split
+#define PT_SPLIT_KEEP 3   // a SPLIT run goes on while at least KEEP/8 of the lanes it started with are still at a Split
 #endif
 #ifndef PT_PIECE_MIN
 #define PT_PIECE_MIN 32       // fewest sample indices in a piece (each piece ends with a drain of the wave)
@@ -55,12 +55,15 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #ifndef PT_ITEMS_PER_SLOT
 #define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
 #endif
+#ifndef PT_LEAF_KEEP
+#define PT_LEAF_KEEP 2    // the same for a LEAF run (a Leaf's next node is often its sibling Leaf): -4.5 %
+#endif
 // vote weights: a SHADE step is the most expensive one, so it waits for more lanes
 #ifndef PT_W_SPLIT
 #define PT_W_SPLIT 4
 #endif
 #ifndef PT_W_LEAF
-#define PT_W_LEAF 8
+#define PT_W_LEAF 5
 #endif
 #ifndef PT_W_SHADE
 #define PT_W_SHADE 1
@@ -331,12 +334,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 }
                 PT_TIME(0);
             } else if (vL >= vZ) {
-                PT_STAT(1, cL);
+                // LEAF run: one Sphere::trace per iteration for the lanes standing on a Leaf
+                const int keepL = (cL * PT_LEAF_KEEP + 7) >> 3;
                 if (code < 0) {
-                    float4 n0, n1;
-                    fetch(code, n0, n1);
-                    leaf_step(n0, n1, ray.o, ray.d, a, h);
-                    code = __float_as_int(n1.w);
+                    for (;;) {
+                        PT_STAT(1, lanes(true));
+                        float4 n0, n1;
+                        fetch(code, n0, n1);
+                        leaf_step(n0, n1, ray.o, ray.d, a, h);
+                        code = __float_as_int(n1.w);
+                        const bool at = code < 0;
+                        const bool few = lanes(at) < keepL;
+                        if ((int)!at | (int)few) break;
+                    }
                 }
                 PT_TIME(1);
             } else break;
