@@ -85,7 +85,7 @@ def rng_range(state, lo, hi):                    # rng.rs:83-85
     return rng_f32(state) * (F(hi) - F(lo)) + F(lo)
 
 
-def path_seed(seed, pixel, sample):              # P3: splitmix64 finaliser, never 0
+def path_stream(seed, pixel, sample):            # P3: stream state after with_seed; splitmix64 finaliser, never 0
     with np.errstate(over="ignore"):
         k = (pixel.astype(U64) << U64(32)) | U64(sample)
         z = U64(seed) + (k + U64(1)) * U64(0x9E3779B97F4A7C15)
@@ -408,7 +408,7 @@ def render(scene, cam, S, seed, sample_range=None):
     pixel = np.arange(npx, dtype=np.uint32)
     for s in range(s0, s1):
         o, d = sample_rays(cam, S, s)
-        rng = rng_with_seed(path_seed(seed, pixel, s))
+        rng = path_stream(seed, pixel, s).copy()
         att = np.ones((npx, 3), F)                              # raytracer.rs:50
         dead = np.zeros(npx, bool)
         active = np.arange(npx)

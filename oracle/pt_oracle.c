@@ -29,8 +29,11 @@
  *       (ora_atan2f / ora_asinf below) rounded once to fp32.
  *   P3  RNG streams: the reference seeds one stream per worker thread from
  *       rdseed (src/rng.rs:4-25, src/parallel_renderer/mod.rs:124), which is
- *       not reproducible.  Here every (pixel, sample) pair owns the stream
- *       Rng::with_seed(mix(seed, pixel, sample)) (ora_path_seed below).
+ *       not reproducible.  Here every (pixel, sample) pair owns one stream whose
+ *       state after construction is mix(seed, pixel, sample) (ora_path_stream
+ *       below), i.e. the stream Rng::with_seed(ora_path_seed(...)): with_seed's
+ *       ten rounds are a bijection on the nonzero states, so naming the state
+ *       names the seed, and the rounds need not be run once per path.
  */
 #include <math.h>
 #include <pthread.h>
@@ -174,9 +177,9 @@ static inline float rng_range(uint64_t *state, float min, float max)
 {
     return ora_rng_f32(state) * (max - min) + min;
 }
-/* P3: per-(pixel,sample) stream seed; splitmix64 finaliser, never 0 (state 0 is
- * the xorshift fixed point, rng.rs:50-60). */
-ORA_API uint64_t ora_path_seed(uint64_t seed, uint32_t pixel, uint32_t sample)
+/* P3: state of the (pixel, sample) stream after Rng::with_seed; splitmix64 finaliser,
+ * never 0 (state 0 is the xorshift fixed point, rng.rs:50-60). */
+ORA_API uint64_t ora_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample)
 {
     uint64_t k = ((uint64_t)pixel << 32) | (uint64_t)sample;
     uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
@@ -185,6 +188,18 @@ ORA_API uint64_t ora_path_seed(uint64_t seed, uint32_t pixel, uint32_t sample)
     z = z ^ (z >> 31);
     if (z == 0) z = 0x9E3779B97F4A7C15ull;
     return z;
+}
+/* the seed that stream is Rng::with_seed of: ten inverse rounds of rng.rs:50-60
+ * (x ^= x << n inverts as x ^= x << n, << 2n, << 4n ...; likewise >>) */
+ORA_API uint64_t ora_path_seed(uint64_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint64_t x = ora_path_stream(seed, pixel, sample);
+    for (int i = 0; i < 10; i++) {
+        x ^= x << 17; x ^= x << 34;
+        x ^= x >> 7;  x ^= x >> 14; x ^= x >> 28; x ^= x >> 56;
+        x ^= x << 13; x ^= x << 26; x ^= x << 52;
+    }
+    return x;
 }
 
 typedef struct { uint64_t state; ora_counters *cnt; } rng_t;
@@ -666,7 +681,7 @@ static v3 trace_pixel_sum(const ora_scene *sc, const ora_camera *cam, int S, uin
     v3 total = vfill(0.0f);
     v3 part = vfill(0.0f);
     for (int s = s0; s < s1; s++) {
-        rng_t rng = {ora_rng_with_seed(ora_path_seed(seed, pixel, (uint32_t)s)), cnt};
+        rng_t rng = {ora_path_stream(seed, pixel, (uint32_t)s), cnt};
         v3 c = trace_ray(sc, sample_ray(cam, S, px, py, s), &rng, cnt);
         if (chunk > 0) {
             part = vadd(part, c);
@@ -842,7 +857,7 @@ ORA_API void ora_trace_path(const ora_scene *sc, const ora_camera *cam, int32_t 
                             int32_t px, int32_t py, int32_t s, float out_rgb[3])
 {
     uint32_t pixel = (uint32_t)(py * cam->width + px);
-    rng_t rng = {ora_rng_with_seed(ora_path_seed(seed, pixel, (uint32_t)s)), NULL};
+    rng_t rng = {ora_path_stream(seed, pixel, (uint32_t)s), NULL};
     v3 c = trace_ray(sc, sample_ray(cam, samples, px, py, s), &rng, NULL);
     out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
 }

@@ -103,7 +103,8 @@ PTD float rng_f32(uint64_t &s)                                                  
     return (float)(v >> 8) / 16777216.0f;
 }
 PTD float rng_range(uint64_t &s, float mn, float mx) { return rng_f32(s) * (mx - mn) + mn; } // rng.rs:83-85
-// P3: seed of the (pixel, sample) stream, then Rng::with_seed (rng.rs:27-35)
+// P3: state of the (pixel, sample) stream after Rng::with_seed (rng.rs:27-35): the stream is
+// with_seed(W^-1(z)) for W = with_seed's ten rounds, a bijection, so the rounds are not run here
 PTD uint64_t path_rng(uint64_t seed, uint32_t pixel, uint32_t sample)
 {
     uint64_t k = ((uint64_t)pixel << 32) | (uint64_t)sample;
@@ -112,8 +113,6 @@ PTD uint64_t path_rng(uint64_t seed, uint32_t pixel, uint32_t sample)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
     if (z == 0) z = 0x9E3779B97F4A7C15ull;
-#pragma unroll
-    for (int i = 0; i < 10; i++) (void)rng_raw(z);
     return z;
 }
 

@@ -96,7 +96,7 @@ int main(int argc, char **argv)
             nS = nL = mism = segs = 0; long paths = 0;
             for (int py = 0; py < 1080; py += 7) for (int px = 0; px < 1920; px += 7) for (int s = 0; s < 256; s += 37) {
                 uint32_t pixel = (uint32_t)(py * 1920 + px);
-                rng_t rng = {ora_rng_with_seed(ora_path_seed(20260711, pixel, (uint32_t)s)), NULL};
+                rng_t rng = {ora_path_stream(20260711, pixel, (uint32_t)s), NULL};
                 xtrace_ray(sc, sample_ray(&cam, 16, px, py, s), &rng); paths++;
             }
             printf("build %s order %s: S/path %.1f L/path %.2f  segs/path %.2f  mismatching segments %ld of %ld\n",

@@ -65,6 +65,7 @@ def load(fast=False):
         L.ora_rng_with_seed.restype, L.ora_rng_with_seed.argtypes = C.c_uint64, [C.c_uint64]
         L.ora_rng_f32.restype, L.ora_rng_f32.argtypes = C.c_float, [C.POINTER(C.c_uint64)]
         L.ora_path_seed.restype, L.ora_path_seed.argtypes = C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_path_stream.restype, L.ora_path_stream.argtypes = C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32]
         L.ora_atan2f.restype, L.ora_atan2f.argtypes = C.c_float, [C.c_float, C.c_float]
         L.ora_asinf.restype, L.ora_asinf.argtypes = C.c_float, [C.c_float]
         L.ora_schlick.restype, L.ora_schlick.argtypes = C.c_float, [C.c_float, C.c_float]

@@ -45,10 +45,20 @@ def test_f32_mapping(oracle):
         assert 0.0 <= got < 1.0
 
 
-def test_path_seed_never_zero_and_distinct(oracle):
+def test_path_stream_never_zero_and_distinct(oracle):
     L = oracle.load()
-    seen = {L.ora_path_seed(7, p, s) for p in range(64) for s in range(64)}
+    seen = {L.ora_path_stream(7, p, s) for p in range(64) for s in range(64)}
     assert len(seen) == 64 * 64 and 0 not in seen
+
+
+def test_path_stream_is_with_seed_of_path_seed(oracle):
+    # P3: the (pixel, sample) stream is named by its state after construction; it is the stream
+    # Rng::with_seed(ora_path_seed(...)) (rng.rs:27-35), whose ten rounds are a bijection
+    L = oracle.load()
+    for seed in (0, 7, 20260711, 2 ** 64 - 1):
+        for p in (0, 1, 63, 1919 * 1080, 2 ** 32 - 1):
+            for s in (0, 1, 99, 4095):
+                assert L.ora_rng_with_seed(L.ora_path_seed(seed, p, s)) == L.ora_path_stream(seed, p, s)
 
 
 def test_schlick(oracle):
