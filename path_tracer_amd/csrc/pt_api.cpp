@@ -344,6 +344,14 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     c->scene.n_spheres = n_spheres;
     c->scene.root_code = code_of(0);
     c->scene.lds_nodes = n_nodes < kMaxLdsNodes ? n_nodes : kMaxLdsNodes;
+    // regular_ray (pt_device.hpp): the short division needs every sphere inside 2^32 (NaN fails the test)
+    bool bounded = true;
+    for (int32_t i = 0; i < n_spheres; i++) {
+        const pt_sphere &s = spheres[i];
+        const float lim = 4294967296.0f;
+        bounded = bounded && std::fabs(s.cx) <= lim && std::fabs(s.cy) <= lim && std::fabs(s.cz) <= lim && std::fabs(s.radius) <= lim;
+    }
+    c->scene.bounded = bounded ? 1 : 0;
     c->have_scene = true;
     return PT_OK;
 }

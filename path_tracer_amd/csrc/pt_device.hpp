@@ -190,6 +190,7 @@ struct Scene {
     int32_t n_nodes, n_spheres;
     int32_t root_code;       // node code of the root
     int32_t lds_nodes;       // n0[0 .. lds_nodes) is staged in LDS by the path kernel
+    int32_t bounded;         // every sphere has |c_i| <= 2^32 and |r| <= 2^32 (see regular_ray)
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;
@@ -331,7 +332,9 @@ PTD int32_t split_step(const float4 n0, const float4 n1, const f3 o, const f3 in
 }
 
 // Sphere::trace (sphere.rs:46-69) for the Leaf whose data is (n0, n1); `a` = dot(d, d)
-PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, const float a, Hit &h)
+// FAST (wave-uniform; REGULAR rays only, see regular_ray): the divisions by a = dot(d, d) go
+// through div_by with ra = RN(1/a), computed once per walk.
+PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, const float a, const float ra, const bool FAST, Hit &h)
 {
     f3 oc = o - mk(n0.x, n0.y, n0.z);
     float b = dot(oc, d);
@@ -339,10 +342,10 @@ PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, con
     float disc = b * b - a * c;
     if (disc > 0.0f) {
         float sq = p_sqrt(disc);
-        float sol = (-b - sq) / a;
+        float sol = FAST ? div_by(-b - sq, a, ra) : (-b - sq) / a;
         if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
         else {
-            sol = (-b + sq) / a;
+            sol = FAST ? div_by(-b + sq, a, ra) : (-b + sq) / a;
             if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
         }
     }
@@ -353,19 +356,37 @@ PTD bool finite3(f3 v)
     return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z);
 }
 
+// REGULAR ray: the class of rays the short exact forms are proven for.
+//  * 1/d finite and o finite: the slab test has no NaN, so the med3 chain of split_step<true>
+//    equals the reference's min/max chain.
+//  * |o_i| < 2^32, a = d.d in [2^-32, 2^32], and every sphere of the scene has |c_i|, |r| <= 2^32
+//    (`bounded`, checked at upload): then in Sphere::trace |b| < 2^51, |disc| < 2^103,
+//    |-b +- sqrt(disc)| < 2^53, nothing overflows, and a root that can be accepted (t > T_MIN)
+//    has every intermediate of div_by far inside the normal range, where the two fused
+//    corrections return the correctly rounded quotient (Markstein; tools/verify/div_recip.hip).
+//    A root below 2^-20 comes out below T_MIN from both forms and is rejected by both.
+PTD bool regular_ray(const f3 inv, const f3 o, const float a, const bool bounded)
+{
+    const float lim = 4294967296.0f;   // 2^32
+    const bool o_ok = __builtin_fabsf(o.x) < lim && __builtin_fabsf(o.y) < lim && __builtin_fabsf(o.z) < lim;
+    const bool a_ok = __float_as_uint(a) - 0x2f800000u <= 0x20000000u;
+    return finite3(inv) && o_ok && a_ok && bounded;
+}
+
 // whole-ray walk (used by the primary-hit kernel; the path kernel runs the same
 // steps from its state machine)
 PTD Hit scene_trace(const Scene &sc, const Ray &ray)
 {
     const f3 inv = mk(p_rcp(ray.d.x), p_rcp(ray.d.y), p_rcp(ray.d.z));           // scene/mod.rs:31: (1,1,1) / dir
-    const bool regular = finite3(inv) && finite3(ray.o);
     const float a = dot(ray.d, ray.d);                                           // sphere.rs:49
+    const bool regular = regular_ray(inv, ray.o, a, sc.bounded != 0);
+    const float ra = rcp_core(a);                                                // read by REGULAR rays only
     Hit h; h.t = T_MAX; h.prim = -1;
     int32_t code = sc.root_code;
     while (code_index(code) < sc.n_nodes) {   // code_index(end code) == n_nodes
         const int i = code_index(code);
         const float4 n0 = sc.n0[i], n1 = sc.n1[i];
-        if (code < 0) { leaf_step(n0, n1, ray.o, ray.d, a, h); code = __float_as_int(n1.w); }
+        if (code < 0) { leaf_step(n0, n1, ray.o, ray.d, a, ra, regular, h); code = __float_as_int(n1.w); }
         else code = regular ? split_step<true>(n0, n1, ray.o, inv, h.t) : split_step<false>(n0, n1, ray.o, inv, h.t);
     }
     return h;

@@ -59,6 +59,9 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #define PT_LEAF_KEEP 2    // the same for a LEAF run (a Leaf's next node is often its sibling Leaf): -4.5 %
 #endif
 // vote weights: a SHADE step is the most expensive one, so it waits for more lanes
+#ifndef PT_FAST_DIV
+#define PT_FAST_DIV 1
+#endif
 #ifndef PT_W_SPLIT
 #define PT_W_SPLIT 4
 #endif
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     const int32_t C_DONE = n_nodes + 1;
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
     f3 inv = fill(0.0f);
-    float a = 0.0f;
+    float a = 0.0f, ra = 0.0f;
     Hit h; h.t = T_MAX; h.prim = -1;
     int32_t code = C_DONE;
     f3 att = fill(1.0f);
@@ -281,8 +284,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         }
         if (new_walk) {
             inv = mk(p_rcp(ray.d.x), p_rcp(ray.d.y), p_rcp(ray.d.z));            // scene/mod.rs:31: (1,1,1) / dir
-            regular = finite3(inv) && finite3(ray.o);
             a = dot(ray.d, ray.d);                                               // sphere.rs:49
+            ra = rcp_core(a);                                                    // read by REGULAR rays only
+            regular = regular_ray(inv, ray.o, a, sc.bounded != 0);
             h.t = T_MAX; h.prim = -1;
             code = sc.root_code;
         }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                         PT_STAT(1, lanes(true));
                         float4 n0, n1;
                         fetch(code, n0, n1);
-                        leaf_step(n0, n1, ray.o, ray.d, a, h);
+                        leaf_step(n0, n1, ray.o, ray.d, a, ra, PT_FAST_DIV && all_regular, h);
                         code = __float_as_int(n1.w);
                         const bool at = code < 0;
                         const bool few = lanes(at) < keepL;

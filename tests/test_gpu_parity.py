@@ -401,3 +401,38 @@ def test_fuzz_scenes_bit_exact(renderer, oracle, k):
     chunk = -(-samples * samples // lanes)
     _, rad2, _ = renderer.render(rt, seed=k, radiance=True)
     assert same_bits(rad2, osc.render(rt.camera.pod, samples, seed=k, chunk=chunk)["radiance"])
+
+
+def _scaled_case(scale, k=3):
+    """The same small scene at very different sizes: sphere centres and radii multiplied by `scale`,
+    seen from the origin (the reference's camera keeps its image plane at distance 1 from the eye,
+    camera.rs, so an eye far from the origin would quantise every direction away)."""
+    import path_tracer_amd as pt
+    rnd = np.random.default_rng(77 + k)
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, -101.0 * scale, -4.0 * scale), 100.0 * scale, pt.Lambertian.new_solid((0.8, 0.8, 0.0))))
+    for i in range(12):
+        c = (rnd.uniform(-1, 1, 3) * np.array([2.5, 1.0, 1.5]) + np.array([0.0, 0.0, -4.5])) * scale
+        r = float(rnd.choice([0.2, 0.5, -0.45, 0.9])) * scale            # negative radius: the hollow-glass idiom
+        mat = [pt.Lambertian.new_solid((0.7, 0.3, 0.3)), pt.Metal.new((0.8, 0.6, 0.2), 0.3), pt.Dielectric.new(1.5)][i % 3]
+        scene.add(pt.Sphere.new(tuple(float(x) for x in c), r, mat))
+    cam = pt.Camera.new((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 60.0, 48, 27)
+    return pt.Raytracer.new(cam, scene, 3), 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2_scale", [-40, -14, -10, -8, 0, 12, 20, 24, 25, 26, 29, 31, 34])
+def test_scaled_scenes_bit_exact(renderer, oracle, log2_scale):
+    """Edges of the REGULAR class (pt_device.hpp regular_ray): the reciprocal-based division of
+    Sphere::trace is used for coordinates below 2^32 and the IEEE division beyond (the ground
+    sphere's radius passes 2^32 at scale 2^26, hit points pass it from 2^24 on), roots straddle
+    T_MIN = 0.001 at the small scales; both must equal the oracle's plain division bit for bit.
+    Beyond 2^35 the reference's BVH build panics (box volumes overflow, bvh.rs:19)."""
+    rt, samples = _scaled_case(2.0 ** log2_scale)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, samples, seed=5, hit_ids=True)
+    img, rad, ids = renderer.render(rt, seed=5, radiance=True, hit_ids=True)
+    assert np.array_equal(ids, ref["hit_id"])
+    lanes = renderer.lanes_per_pixel(samples, 0, samples * samples)
+    chunk = -(-samples * samples // lanes)
+    assert same_bits(rad, osc.render(rt.camera.pod, samples, seed=5, chunk=chunk)["radiance"])

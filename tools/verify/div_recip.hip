@@ -25,20 +25,20 @@ __global__ void check(unsigned long long *bad, uint32_t *first, uint64_t seed, i
     const uint64_t id = seed + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int k = 0; k < 64; k++) {
         uint64_t h = mix(id * 64 + k);
-        // a: mantissa random (biased to extremes), exponent in [-30, 30]
+        // a: mantissa random (biased to extremes), exponent in [-32, 32] (regular_ray)
         uint32_t am = (uint32_t)h & 0x7fffffu;
         if ((h >> 60) == 0) am = 0x7fffffu - (am & 0xff);
         if ((h >> 60) == 1) am = am & 0xff;
-        int ae = (int)((h >> 23) % 61) - 30;
+        int ae = (int)((h >> 23) % 65) - 32;
         float a = __uint_as_float(((uint32_t)(ae + 127) << 23) | am);
         uint64_t g = mix(h);
         float x;
         if (mode == 0) {
-            uint32_t xm = (uint32_t)g & 0x7fffffu; int xe = (int)((g >> 23) % 101) - 50;
+            uint32_t xm = (uint32_t)g & 0x7fffffu; int xe = (int)((g >> 23) % 121) - 60;
             x = __uint_as_float(((uint32_t)(g >> 63) << 31) | ((uint32_t)(xe + 127) << 23) | xm);
         } else {
             // x = RN(a * (m + half an ulp)) +- few ulps: quotient next to a midpoint
-            uint32_t qm = (uint32_t)g & 0x7fffffu; int qe = (int)((g >> 23) % 61) - 30;
+            uint32_t qm = (uint32_t)g & 0x7fffffu; int qe = (int)((g >> 23) % 61) - 9;
             double m = (double)__uint_as_float(((uint32_t)(qe + 127) << 23) | qm);
             double mid = m * (1.0 + 0.0) + (double)__uint_as_float((uint32_t)(qe + 127 - 24) << 23);
             float x0 = (float)((double)a * mid);
