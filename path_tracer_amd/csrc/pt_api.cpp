@@ -3,6 +3,7 @@
 // and the kernels in pt_kernels.hip.  No exception leaves this file.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -159,13 +160,15 @@ int pt_create(int32_t device, pt_context **out)
     pt_context *c = new (std::nothrow) pt_context();
     if (!c) return fail(nullptr, PT_ERR_INVALID, "out of host memory");
     c->device = device;
-    PT_HIP(nullptr, hipSetDevice(device));
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
     if (e != hipSuccess) {
+        if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail(nullptr, PT_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+        return fail(nullptr, PT_ERR_HIP, "device binding / stream / event creation failed: %s", hipGetErrorString(e));
     }
     *out = c;
     return PT_OK;
@@ -219,8 +222,8 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     for (int32_t i = 0; i < n_materials; i++) {
         const pt_material &m = materials[i];
         if (m.kind < PT_LAMBERTIAN || m.kind > PT_DIELECTRIC) return fail(c, PT_ERR_INVALID, "material %d: unknown kind %d", i, m.kind);
-        if (m.kind == PT_LAMBERTIAN && m.texture >= n_textures)
-            return fail(c, PT_ERR_INVALID, "material %d: texture index %d out of range [0, %d)", i, m.texture, n_textures);
+        if (m.kind == PT_LAMBERTIAN && (m.texture < -1 || m.texture >= n_textures))
+            return fail(c, PT_ERR_INVALID, "material %d: texture index %d not -1 or in [0, %d)", i, m.texture, n_textures);
     }
     for (int32_t i = 0; i < n_textures; i++)
         if (!textures[i].rgb8 || textures[i].width < 1 || textures[i].height < 1)
@@ -276,7 +279,11 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     for (size_t q = 0; q < order.size(); q++) {
         const int32_t i = order[q];
         slot[i] = (int32_t)q;
-        if (nodes[i].prim < 0) { order.push_back(i + 1); order.push_back(nodes[i + 1].skip); }
+        if (nodes[i].prim < 0) {
+            if (order.size() + 2 > (size_t)n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");   // stays within the reservation
+            order.push_back(i + 1);
+            order.push_back(nodes[i + 1].skip);
+        }
     }
     if ((int32_t)order.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
     // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
@@ -322,7 +329,13 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_prims, h_prims.data(), h_prims.size() * sizeof(float4), hipMemcpyHostToDevice));
     if (n_textures > 0) {
-        std::vector<ptd::Texture> h_tex((size_t)n_textures);
+        std::vector<ptd::Texture> h_tex;
+        try {
+            h_tex.resize((size_t)n_textures);
+            c->d_texels.reserve((size_t)n_textures);
+        } catch (...) {
+            return fail(c, PT_ERR_INVALID, "out of host memory");
+        }
         for (int32_t i = 0; i < n_textures; i++) {
             const size_t bytes = (size_t)textures[i].width * (size_t)textures[i].height * 3;
             uint8_t *d = nullptr;
