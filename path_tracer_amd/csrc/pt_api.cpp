@@ -334,6 +334,9 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
         std::memcpy(&a.w, &tag, 4);
         h_prims[2 * (size_t)i] = a;
         h_prims[2 * (size_t)i + 1] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
+        // a Dielectric has no albedo: the slots carry the two values its scatter derives from ref_idx
+        // alone, math/mod.rs:37-38 and dielectric.rs:41, computed here with the same fp32 operations
+        if (m.kind == PT_DIELECTRIC) h_prims[2 * (size_t)i + 1] = make_float4(ptd::schlick_r0(m.param), 1.0f / m.param, 0.0f, m.param);
     }
 
     PT_HIP(c, hipSetDevice(c->device));

@@ -135,10 +135,14 @@ PTD bool refract(f3 d, f3 n, float k, f3 &out)                                  
     }
     return false;
 }
-PTD float schlick(float cosine, float ref_idx)                                   // math/mod.rs:36-45 (v^5 as written)
+// r0 of math/mod.rs:37-38, a function of the material alone: computed once at upload (same fp32 ops)
+inline __host__ __device__ float schlick_r0(float ref_idx)
 {
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-    r0 = r0 * r0;
+    return r0 * r0;
+}
+PTD float schlick(float cosine, float r0)                                        // math/mod.rs:36-45 (v^5 as written), from r0 on
+{
     float v = r0 + (1.0f - r0) * (1.0f - cosine);
     float v2 = v * v;
     float v4 = v2 * v2;
@@ -184,7 +188,7 @@ struct Scene {
     const float4 *n0, *n1;   // one float4 each per node (layout below)
     // per primitive (Scene::add order), 32 bytes = one half cache line for a hit's two loads:
     //   prims[2 i]     = (cx, cy, cz, bits(kind | (texture index + 1) << 2))
-    //   prims[2 i + 1] = its material's (albedo r, g, b, param)
+    //   prims[2 i + 1] = its material's (albedo r, g, b, param); a Dielectric's: (schlick r0, 1 / ref_idx, -, ref_idx)
     const float4 *prims;
     const Texture *textures;
     int32_t n_nodes, n_spheres;
@@ -429,12 +433,12 @@ PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f
         const float dt = dot(dir, n);
         f3 outward; float ni_over_nt, cosine;
         if (dt > 0.0f) { cosine = ref_idx * dt; outward = neg(n); ni_over_nt = ref_idx; }
-        else { cosine = -dt; outward = n; ni_over_nt = p_rcp(ref_idx); }
+        else { cosine = -dt; outward = n; ni_over_nt = ma.y; }                   // 1.0 / ref_idx (dielectric.rs:41), divided at upload
         f3 refracted;
         att = fill(1.0f);
         nd = reflected;
         if (refract(dir, outward, ni_over_nt, refracted)) {
-            float prob = schlick(cosine, ref_idx);
+            float prob = schlick(cosine, ma.x);
             float r = rng_f32(rng);
             nd = (r < prob) ? reflected : refracted;
         }
