@@ -187,6 +187,13 @@ int pt_selftest_unary(pt_context *ctx, int32_t fn, uint64_t *mismatches);
  * `samples`, computed the way the path kernel does (reciprocal + fused corrections) against the
  * IEEE divisions of the reference; returns the number that differ.  The library relies on 0. */
 int pt_selftest_grid(pt_context *ctx, int32_t samples, uint64_t *mismatches);
+/* Self-test, no counterpart in the reference: the division x / a of sphere.rs:55,62 the way the
+ * path kernel does it for REGULAR rays (a's correctly rounded reciprocal, taken once per walk, and
+ * two fused corrections) against the IEEE division, on 2^log2_pairs operand pairs (16..40): a over
+ * the class's whole range [2^-32, 2^32], half of the numerators random below 2^53, half built so
+ * that the quotient lies within two ulps of a rounding midpoint.  Not exhaustive (2^64 pairs
+ * exist); the proof is Markstein's theorem, this is its check.  Returns the number that differ. */
+int pt_selftest_division(pt_context *ctx, int32_t log2_pairs, uint64_t *mismatches);
 
 /* ---- host-side helpers (pure CPU, no GPU needed) ------------------------- */
 

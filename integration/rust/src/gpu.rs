@@ -40,6 +40,7 @@ extern "C" {
     // optional start-up checks (include/pt_amd.h): both must report 0 mismatches
     pub fn pt_selftest_unary(ctx: *mut pt_context, func: i32, mismatches: *mut u64) -> c_int;
     pub fn pt_selftest_grid(ctx: *mut pt_context, samples: i32, mismatches: *mut u64) -> c_int;
+    pub fn pt_selftest_division(ctx: *mut pt_context, log2_pairs: i32, mismatches: *mut u64) -> c_int;
 }
 
 /// What each `impl Material` / `impl Texture` / `impl Traceable` adds so that the type-erased

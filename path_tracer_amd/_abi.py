@@ -67,6 +67,7 @@ SIGNATURES = {
     "pt_get_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_selftest_unary": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_selftest_grid": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "pt_selftest_division": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_bvh_build": (C.c_int32, [C.POINTER(PtSphere), C.c_int32, C.POINTER(PtBvhNode), C.c_int32]),
     "pt_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                     C.c_int32, C.c_int32, C.POINTER(PtCamera)]),

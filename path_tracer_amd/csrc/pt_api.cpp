@@ -429,6 +429,24 @@ int pt_selftest_unary(pt_context *c, int32_t fn, uint64_t *mismatches)
     return PT_OK;
 }
 
+int pt_selftest_division(pt_context *c, int32_t log2_pairs, uint64_t *mismatches)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (log2_pairs < 16 || log2_pairs > 40 || !mismatches)
+        return fail(c, PT_ERR_INVALID, "pt_selftest_division: log2_pairs must be in [16, 40] and mismatches non-NULL");
+    PT_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_count = nullptr, h_count = 0;
+    PT_HIP(c, hipMalloc((void **)&d_count, sizeof h_count));
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof h_count, c->stream);
+    if (e == hipSuccess) e = ptk::launch_division_selftest(log2_pairs, d_count, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_count);
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, "pt_selftest_division failed: %s", hipGetErrorString(e));
+    *mismatches = h_count;
+    return PT_OK;
+}
+
 int pt_selftest_grid(pt_context *c, int32_t samples, uint64_t *mismatches)
 {
     int rc = check_ready(c, samples);

@@ -487,7 +487,64 @@ __global__ __launch_bounds__(256) void grid_selftest_kernel(unsigned long long *
 
 }  // namespace
 
+// pt_selftest_division: 64 operand pairs (x, a) per lane for Sphere::trace's division x / a through
+// ra = RN(1/a) (pt_device.hpp div_by, regular_ray): a over the whole REGULAR range [2^-32, 2^32]
+// with mantissas biased to the ends of the binade; x random (mode 0) or built so that x / a lies
+// within two ulps of a rounding midpoint (mode 1), the case a division algorithm gets wrong first.
+__device__ __forceinline__ uint64_t selftest_mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void division_selftest_kernel(unsigned long long *count, uint64_t first, int mode)
+{
+    const uint64_t id = first + (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    unsigned bad = 0;
+    for (int k = 0; k < 64; k++) {
+        const uint64_t h = selftest_mix(id * 64 + (uint64_t)k);
+        uint32_t am = (uint32_t)h & 0x7fffffu;
+        if ((h >> 60) == 0) am = 0x7fffffu - (am & 0xffu);
+        if ((h >> 60) == 1) am = am & 0xffu;
+        int ae = (int)((h >> 23) % 65) - 32;
+        if (ae == 32) am = 0;                                                    // the range ends AT 2^32
+        const float a = __uint_as_float(((uint32_t)(ae + 127) << 23) | am);
+        const uint64_t g = selftest_mix(h);
+        float x;
+        if (mode == 0) {
+            const uint32_t xm = (uint32_t)g & 0x7fffffu;
+            const int xe = (int)((g >> 23) % 107) - 53;                          // |x| < 2^53 (regular_ray)
+            x = __uint_as_float(((uint32_t)(g >> 63) << 31) | ((uint32_t)(xe + 127) << 23) | xm);
+        } else {
+            const uint32_t qm = (uint32_t)g & 0x7fffffu;
+            const int qe = (int)((g >> 23) % 40) - 9;                            // quotient in [2^-9, 2^30]: around and above T_MIN
+            const double q = (double)__uint_as_float(((uint32_t)(qe + 127) << 23) | qm);
+            const double mid = q + (double)__uint_as_float((uint32_t)(qe + 127 - 24) << 23);   // half an ulp above q
+            const float x0 = (float)((double)a * mid);
+            x = __uint_as_float(__float_as_uint(x0) + (uint32_t)((int)((g >> 40) % 5) - 2));
+            if ((g >> 62) & 1) x = -x;
+        }
+        const float ref = x / a, got = div_by(x, a, rcp_core(a));
+        if (__float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) bad++;
+    }
+    if (bad) atomicAdd(count, (unsigned long long)bad);
+}
+
 namespace ptk {
+
+hipError_t launch_division_selftest(int log2_pairs, unsigned long long *d_count, hipStream_t stream)
+{
+    // 2^log2_pairs operand pairs, half of them random and half next to midpoints; 64 per lane
+    const uint64_t lanes = (1ull << log2_pairs) / 64 / 2;
+    for (int mode = 0; mode < 2; mode++)
+        for (uint64_t first = 0; first < lanes; first += (1ull << 28)) {
+            const uint64_t n = lanes - first < (1ull << 28) ? lanes - first : (1ull << 28);
+            hipLaunchKernelGGL(division_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_count,
+                               first + ((uint64_t)mode << 60), mode);
+        }
+    return hipGetLastError();
+}
 
 hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, float inv_w, float inv_h, unsigned long long *d_count,
                                 hipStream_t stream)

@@ -26,6 +26,8 @@ namespace ptk {
 int tiles_for(const ptd::Camera &cam, int lanes);
 // counts, into *d_count, the fp32 bit patterns for which short form `fn` differs from the IEEE operation
 hipError_t launch_unary_selftest(int fn, unsigned long long *d_count, hipStream_t stream);
+// counts the operand pairs (2^log2_pairs of them) on which the reciprocal-based division differs from x / a
+hipError_t launch_division_selftest(int log2_pairs, unsigned long long *d_count, hipStream_t stream);
 hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, float inv_w, float inv_h, unsigned long long *d_count,
                                 hipStream_t stream);
 hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,

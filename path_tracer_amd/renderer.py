@@ -137,6 +137,13 @@ class ParallelRenderer:
         _abi.check(self._ctx, _abi.lib().pt_selftest_grid(self._ctx, int(samples), C.byref(n)))
         return int(n.value)
 
+    def selftest_division(self, log2_pairs=34):
+        """pt_selftest_division: operand pairs (of 2^log2_pairs) on which the reciprocal-based
+        division of Sphere::trace differs from the IEEE division."""
+        n = C.c_uint64(0)
+        _abi.check(self._ctx, _abi.lib().pt_selftest_division(self._ctx, int(log2_pairs), C.byref(n)))
+        return int(n.value)
+
     def selftest_unary(self, fn):
         """pt_selftest_unary: inputs (of all 2^32) on which short form `fn` (0: 1/x, 1: sqrt,
         2: 1/sqrt) differs from the IEEE operation."""

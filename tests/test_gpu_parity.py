@@ -295,6 +295,14 @@ def test_unary_short_forms(renderer, fn):
 
 
 @pytest.mark.gpu
+def test_reciprocal_division(renderer):
+    """Sphere::trace's x / a through RN(1/a) and two fused corrections (pt_device.hpp div_by) equals
+    the IEEE division on 2^34 operand pairs over the REGULAR class, half of them next to rounding
+    midpoints (bit-exact bar; the class's edges in scenes: test_scaled_scenes_bit_exact)."""
+    assert renderer.selftest_division(34) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size,samples", [((1920, 1080), 64), ((1920, 1080), 16), ((3840, 2160), 32), ((400, 225), 10),
                                            ((1023, 767), 7), ((16, 9), 2), ((8191, 4099), 33)])
 def test_sample_grid_division(renderer, size, samples):
