@@ -267,6 +267,24 @@ def test_full_size_properties_1080p(renderer, oracle):
     assert np.isfinite(a[1]).all() and (a[1] >= 0).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,s", [("rtow", 1920, 1080, 6), ("simple", 1920, 1080, 8), ("reference", 3840, 2160, 3)],
+                         ids=["cfg3-frame", "cfg2-frame", "cfg5-frame"])
+def test_full_frames_bit_exact(renderer, oracle, kind, w, h, s):
+    """The BASELINE frames at their real sizes and scenes, at a sample count the oracle finishes in
+    seconds on the box's host cores (36-64 spp: pieces, one lane per pixel): every radiance sum and
+    every primary hit id equals the oracle's bit for bit."""
+    rt = make_raytracer(kind, w, h, s)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, s, seed=RENDER_SEED, hit_ids=True)
+    renderer.bind(rt)
+    assert renderer.lanes_per_pixel(s, 0, s * s) == 1
+    img, rad, ids = renderer.render(rt, seed=RENDER_SEED, radiance=True, hit_ids=True)
+    assert np.array_equal(ids, ref["hit_id"])
+    assert same_bits(rad, ref["radiance"])
+    assert np.array_equal(img, osc.resolve(ref["radiance"], s))
+
+
 def test_cfg1_frame_against_oracle(renderer, oracle):
     """BASELINE config 1 at its real size: RTOW scene 400x225 @ 100 spp (9 M paths; the oracle
     needs a few seconds).  Auto lanes-per-pixel (8): bit-exact against the oracle's chunked sum,
