@@ -3,7 +3,8 @@ RTOW final scene 1920x1080 @ 4096 spp, 8.49 G paths -- rendered by the library a
 oracle's sequential render of the same frame: every fp32 radiance sum, bit for bit.
 Too long for the test suite (tests/test_gpu_parity.py::test_full_frames_bit_exact runs the same
 frame at 36 spp); the result of the last run is recorded in DESIGN.md.
-    python3 tools/full_frame_check.py [samples]      -> gpurun_out/full_frame_check.json
+    python3 tools/full_frame_check.py [workload [samples]]      -> gpurun_out/full_frame_check_<workload>.json
+(workload: a key of bench.WORKLOADS; "largest" = config 5, 3840x2160 @ 1024 spp, takes ~9 minutes)
 """
 import json
 import os
@@ -21,8 +22,11 @@ import bench  # noqa: E402
 import oracle_lib  # noqa: E402   (the checker)
 import path_tracer_amd as pt  # noqa: E402
 
-samples = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-rt = bench.build_raytracer(pt, "rtow", 1920, 1080, samples)
+workload = sys.argv[1] if len(sys.argv) > 1 else "final"
+scene_kind, width, height, samples, _desc = bench.WORKLOADS[workload]
+if len(sys.argv) > 2:
+    samples = int(sys.argv[2])
+rt = bench.build_raytracer(pt, scene_kind, width, height, samples)
 r = pt.ParallelRenderer.new(0)
 t0 = time.time()
 img, rad, ids = r.render(rt, seed=bench.RENDER_SEED, radiance=True, hit_ids=True)
@@ -47,10 +51,11 @@ same = bool(np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
 ids_same = bool(np.array_equal(ids, ref["hit_id"]))
 img_same = bool(np.array_equal(img, osc.resolve(ref["radiance"], samples)))
 diff = int((rad.view(np.uint32) != ref["radiance"].view(np.uint32)).sum())
-out = {"frame": "1920x1080", "samples": samples, "spp": samples * samples, "paths": 1920 * 1080 * samples * samples,
+out = {"workload": workload, "frame": "%dx%d" % (width, height), "samples": samples, "spp": samples * samples,
+       "paths": width * height * samples * samples,
        "radiance_bit_exact": same, "differing_words": diff, "hit_ids_equal": ids_same, "image_equal": img_same,
        "gpu_seconds": round(t_gpu, 3), "oracle_seconds_16_threads": round(t_cpu, 1)}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "full_frame_check.json"), "w"))
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "full_frame_check_%s.json" % workload), "w"))
 sys.exit(0 if same and ids_same and img_same else 1)
