@@ -150,6 +150,21 @@ int pt_resolve_device(pt_context *ctx, int32_t samples, const float *d_radiance,
 int pt_primary_hits_device(pt_context *ctx, int32_t samples, int32_t sample_index, int32_t *d_hit_id,
                            float *d_hit_t, void *stream);
 
+/* pt_render_device for callers that cannot allocate.  No counterpart in the reference: it is for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
+ * arguments, same launch, same results bit for bit; the only difference is where the launch's
+ * work-distribution scratch (ticket counter, error word, one progress word per 8x8 tile) lives:
+ * in a file-scope __device__ array of the library (1 MiB + 256 B on every GPU the library runs on,
+ * held until the process ends) instead of the buffer pt_set_camera allocates.  The call itself
+ * performs no hipMalloc / hipFree / allocating library call.
+ *   limit : frames of at most 262,144 8x8 tiles (16.7 M pixels; 3840x2160 has 129,600); larger
+ *           frames return PT_ERR_LIMIT.
+ *   sharing: ALL contexts on one GPU share that GPU's array (it is cleared at the start of every
+ *           launch), so launches of this entry point that overlap in time on one GPU -- from
+ *           different streams or different contexts -- race.  Issue them on one stream at a time. */
+int pt_render_device_static(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
+                            int32_t sample_end, int32_t accumulate, float *d_radiance, void *stream);
+
 /* pt_render in `passes` launches over consecutive sample-index ranges, calling
  * progress(user, samples_done, samples_total) on the calling thread after each one: the
  * counterpart of Statistics::pixels_done + the reporter thread (src/raytracer.rs:108-116,

@@ -58,6 +58,8 @@ SIGNATURES = {
                             C.c_void_p]),
     "pt_render_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
+    "pt_render_device_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p]),
     "pt_render_progress": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "pt_resolve_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -55,6 +55,10 @@ struct pt_context {
 
     int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
     size_t sched_bytes = 0;
+    // the device's copy of the library's file-scope scratch array (pt_render_device_static), resolved in pt_create
+    int32_t *static_sched = nullptr;
+    size_t static_sched_bytes = 0;
+    int32_t *last_sched = nullptr;   // the scratch the most recent path-kernel launch used (its error word)
 };
 
 namespace {
@@ -164,6 +168,9 @@ int pt_create(int32_t device, pt_context **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    // each GPU holds its own copy of the scratch array at its own address: resolved here, with this
+    // context's device current, and used through this pointer only
+    if (e == hipSuccess) e = ptk::static_sched(device, &c->static_sched, &c->static_sched_bytes);
     if (e != hipSuccess) {
         if (c->ev_start) (void)hipEventDestroy(c->ev_start);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -403,6 +410,7 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
     if (need > c->sched_bytes) {
         PT_HIP(c, hipSetDevice(c->device));
         PT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->last_sched == c->d_sched) c->last_sched = nullptr;
         if (c->d_sched) (void)hipFree(c->d_sched);
         c->d_sched = nullptr;
         c->sched_bytes = 0;
@@ -482,8 +490,9 @@ int pt_get_lanes_per_pixel(const pt_context *c, int32_t samples, int32_t sample_
     return pick_lanes(c, sample_end - sample_begin);
 }
 
-int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end,
-                     int32_t accumulate, float *d_radiance, void *stream)
+// pt_render_device / pt_render_device_static: one path-kernel launch whose work-distribution scratch is `sched`
+static int render_device_with(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end,
+                              int32_t accumulate, float *d_radiance, void *stream, int32_t *sched)
 {
     int rc = check_ready(c, samples);
     if (rc != PT_OK) return rc;
@@ -510,7 +519,8 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     rp.stats = d_stats;
 #endif
     PT_HIP(c, hipEventRecord(c->ev_start, st));
-    PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, c->d_sched, d_radiance, st));
+    c->last_sched = sched;
+    PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
     PT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->timed = true;
 #ifdef PT_STATS
@@ -529,6 +539,26 @@ int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t samp
     }
 #endif
     return PT_OK;
+}
+
+int pt_render_device(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end,
+                     int32_t accumulate, float *d_radiance, void *stream)
+{
+    if (!c) return PT_ERR_INVALID;
+    return render_device_with(c, samples, seed, sample_begin, sample_end, accumulate, d_radiance, stream, c->d_sched);
+}
+
+int pt_render_device_static(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begin, int32_t sample_end,
+                            int32_t accumulate, float *d_radiance, void *stream)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!c->static_sched) return fail(c, PT_ERR_HIP, "the library's scratch array was not resolved on device %d", c->device);
+    if (c->have_camera && ptk::sched_bytes(c->camera) > c->static_sched_bytes)
+        return fail(c, PT_ERR_LIMIT, "pt_render_device_static: a %d x %d frame needs %zu bytes of scratch, the built-in array holds %zu "
+                                     "(frames up to %d 8x8 tiles); use pt_render_device",
+                    c->camera.width, c->camera.height, ptk::sched_bytes(c->camera), c->static_sched_bytes,
+                    (int)((c->static_sched_bytes / sizeof(int32_t)) - 64));
+    return render_device_with(c, samples, seed, sample_begin, sample_end, accumulate, d_radiance, stream, c->static_sched);
 }
 
 int pt_resolve_device(pt_context *c, int32_t samples, const float *d_radiance, uint8_t *d_rgb8, void *stream)
@@ -584,7 +614,7 @@ int pt_render(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begi
     if (rgb8 || radiance) {
         // the kernel's bounded dependency wait (pt_kernels.hip) reports here instead of hanging
         int32_t ctrl[2] = {0, 0};
-        PT_HIP(c, hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost));
+        PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
         if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
         if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
     }
@@ -608,7 +638,7 @@ int pt_render_progress(pt_context *c, int32_t samples, uint64_t seed, int32_t pa
         if (rc != PT_OK) return rc;
         PT_HIP(c, hipStreamSynchronize(c->stream));
         int32_t ctrl[2] = {0, 0};
-        PT_HIP(c, hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost));
+        PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
         if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
         if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
         if (progress && progress(user, end, total) != 0)
@@ -633,7 +663,7 @@ float pt_last_path_kernel_ms(pt_context *c)
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0f;
     // the launch is complete: its error word can be read (see pt_render)
     int32_t ctrl[2] = {0, 0};
-    if (c->d_sched && hipMemcpy(ctrl, c->d_sched, sizeof ctrl, hipMemcpyDeviceToHost) == hipSuccess && ctrl[1] != 0) {
+    if (c->last_sched && hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost) == hipSuccess && ctrl[1] != 0) {
         (void)fail(c, PT_ERR_HIP, ctrl[1] == 2 ? "path kernel: dynamic LDS does not start at address 0"
                                                : "path kernel: a piece gave up waiting for its predecessor");
         return -2.0f;

@@ -6,6 +6,8 @@
 //   K3 resolve_kernel     : sqrt(sum / S^2) * 255 -> u8 (src/raytracer.rs:92-93,119-121)
 //
 // Compiled with -ffp-contract=off (see pt_device.hpp).
+#include <mutex>
+
 #include "pt_kernels.hpp"
 
 using namespace ptd;
@@ -531,7 +533,35 @@ __global__ __launch_bounds__(256) void division_selftest_kernel(unsigned long lo
     if (bad) atomicAdd(count, (unsigned long long)bad);
 }
 
+// Scratch of pt_render_device_static (include/pt_amd.h): the work-distribution words of one
+// path-kernel launch (SchedParams: 64 control words + one `done` word per 8x8 tile), for callers
+// that cannot allocate.  Each GPU the library runs on holds its own copy of this array until the
+// process ends; host code never uses the array's name as an address -- ptk::static_sched resolves the
+// device address once per device and the launches take that pointer like any other buffer.
+constexpr int kStaticSchedTiles = 1 << 18;                  // 8x8 tiles: frames up to 16.7 M pixels (a 4K frame has 129,600)
+constexpr int kStaticSchedWords = 64 + kStaticSchedTiles;   // 1 MiB + 256 B
+static __device__ __align__(256) int32_t scratch[kStaticSchedWords];
+
 namespace ptk {
+
+// Device address and size of `scratch` on `device`, which must be the CURRENT device (pt_create
+// calls this right after hipSetDevice).  Resolved once per device and kept: every GPU holds its own
+// copy of the array at its own address.
+hipError_t static_sched(int device, int32_t **out, size_t *bytes)
+{
+    constexpr int kMaxDevices = 64;
+    static std::mutex lock;
+    static int32_t *resolved[kMaxDevices] = {};
+    *bytes = sizeof(int32_t) * (size_t)kStaticSchedWords;
+    std::lock_guard<std::mutex> guard(lock);
+    if (device >= 0 && device < kMaxDevices && resolved[device]) { *out = resolved[device]; return hipSuccess; }
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (device >= 0 && device < kMaxDevices) resolved[device] = (int32_t *)p;
+    *out = (int32_t *)p;
+    return hipSuccess;
+}
 
 hipError_t launch_division_selftest(int log2_pairs, unsigned long long *d_count, hipStream_t stream)
 {

@@ -33,6 +33,8 @@ hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, floa
 hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
                        float *d_radiance, hipStream_t stream);
 size_t sched_bytes(const ptd::Camera &cam);
+// address and size of the library's file-scope scratch array on the current device (pt_render_device_static)
+hipError_t static_sched(int device, int32_t **out, size_t *bytes);
 hipError_t launch_primary_hits(const ptd::Scene &sc, const ptd::Camera &cam, int S, int sample, int32_t *d_hit_id,
                                float *d_hit_t, hipStream_t stream);
 hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t *d_rgb8, hipStream_t stream);

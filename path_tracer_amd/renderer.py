@@ -104,11 +104,15 @@ class ParallelRenderer:
         return (buffer, rad) if radiance else buffer
 
     # -- device-resident halves (spp-sharded multi-GPU) -----------------------------
-    def render_device(self, raytracer, d_radiance_ptr, seed=0, sample_range=None, accumulate=False, stream=None):
+    def render_device(self, raytracer, d_radiance_ptr, seed=0, sample_range=None, accumulate=False, stream=None,
+                      static_scratch=False):
+        """pt_render_device; ``static_scratch`` = pt_render_device_static, the variant that allocates
+        nothing (bind the raytracer beforehand: binding uploads, which allocates)."""
         self.bind(raytracer)
         s = raytracer.samples
         s0, s1 = sample_range if sample_range is not None else (0, s * s)
-        _abi.check(self._ctx, _abi.lib().pt_render_device(
+        fn = _abi.lib().pt_render_device_static if static_scratch else _abi.lib().pt_render_device
+        _abi.check(self._ctx, fn(
             self._ctx, s, int(seed) & (2 ** 64 - 1), int(s0), int(s1), 1 if accumulate else 0,
             C.c_void_p(d_radiance_ptr), C.c_void_p(stream) if stream else None))
 
