@@ -140,8 +140,9 @@ int pt_render(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_be
  *   pt_resolve_device: d_rgb8[W*H*3] from d_radiance (raytracer.rs:92-93,119-121)
  *   pt_primary_hits_device: d_hit_id[W*H] (and optional d_hit_t[W*H]) for sample index s
  * The launches of one context share its work-distribution scratch: issue them on ONE stream
- * at a time (back-to-back launches on the same stream are ordered and fine; two streams at
- * once race).  A dependency wait that gives up inside the path kernel (never observed) is
+ * at a time (back-to-back launches on the same stream are ordered and fine).  pt_render_device on a
+ * second stream while the context's previous launch is still running returns PT_ERR_INVALID
+ * instead of racing.  A dependency wait that gives up inside the path kernel (never observed) is
  * reported by pt_last_path_kernel_ms (-2) and by pt_render / pt_render_progress (PT_ERR_HIP),
  * not by these asynchronous calls. */
 int pt_render_device(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
@@ -206,7 +207,8 @@ int pt_selftest_grid(pt_context *ctx, int32_t samples, uint64_t *mismatches);
  * path kernel does it for REGULAR rays (a's correctly rounded reciprocal, taken once per walk, and
  * two fused corrections) against the IEEE division, on 2^log2_pairs operand pairs (16..40): a over
  * the class's whole range [2^-32, 2^32], half of the numerators random below 2^53, half built so
- * that the quotient lies within two ulps of a rounding midpoint.  Not exhaustive (2^64 pairs
+ * that the quotient lies within two ulps of a rounding midpoint; then half as many pairs again with a's
+ * mantissa pinned to all ones (a = dot(d, d) of a normalised direction).  Not exhaustive (2^64 pairs
  * exist); the proof is Markstein's theorem, this is its check.  Returns the number that differ. */
 int pt_selftest_division(pt_context *ctx, int32_t log2_pairs, uint64_t *mismatches);
 

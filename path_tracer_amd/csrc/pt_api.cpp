@@ -59,6 +59,7 @@ struct pt_context {
     int32_t *static_sched = nullptr;
     size_t static_sched_bytes = 0;
     int32_t *last_sched = nullptr;   // the scratch the most recent path-kernel launch used (its error word)
+    hipStream_t last_stream = nullptr;   // and the stream it went to
 };
 
 namespace {
@@ -222,7 +223,10 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     if (!spheres || n_spheres < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one sphere (bvh.rs:19)");
     if (!materials || n_materials < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one material");
     if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, PT_ERR_INVALID, "bad texture array");
-    if (n_spheres > (1 << 28)) return fail(c, PT_ERR_LIMIT, "too many spheres (%d)", n_spheres);
+    // node codes are byte offsets (16 * slot) in an int32 with the sign bit as the Leaf flag, and the
+    // buffer resource's size is 16 * n_nodes: 2 * n_spheres - 1 nodes must stay below 2^(31 - PT_CODE_SHIFT)
+    if (n_spheres > (1 << (30 - PT_CODE_SHIFT)))
+        return fail(c, PT_ERR_LIMIT, "too many spheres (%d): the node encoding holds at most %d", n_spheres, 1 << (30 - PT_CODE_SHIFT));
     for (int32_t i = 0; i < n_spheres; i++)
         if (spheres[i].material < 0 || spheres[i].material >= n_materials)
             return fail(c, PT_ERR_INVALID, "sphere %d: material index %d out of range [0, %d)", i, spheres[i].material, n_materials);
@@ -246,6 +250,8 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
             return fail(c, PT_ERR_INVALID, "out of host memory");
         }
         const int32_t got = pt_bvh_build(spheres, n_spheres, built.data(), expect);
+        if (got == PT_ERR_INVALID)
+            return fail(c, PT_ERR_INVALID, "BVH build: degenerate bounds (zero volume or non-finite) -- the reference panics here (bvh.rs:19)");
         if (got != expect) return fail(c, PT_ERR_INVALID, "BVH build failed (%d)", got);
         nodes = built.data();
         n_nodes = got;
@@ -399,24 +405,32 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
     if (!c || !cam) return PT_ERR_INVALID;
     if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height > (1ll << 28))
         return fail(c, PT_ERR_INVALID, "bad frame size %d x %d", cam->width, cam->height);
-    c->camera.llc = ptd::f3{cam->lower_left_corner[0], cam->lower_left_corner[1], cam->lower_left_corner[2]};
-    c->camera.origin = ptd::f3{cam->origin[0], cam->origin[1], cam->origin[2]};
-    c->camera.horizontal = ptd::f3{cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]};
-    c->camera.vertical = ptd::f3{cam->vertical[0], cam->vertical[1], cam->vertical[2]};
-    c->camera.width = cam->width;
-    c->camera.height = cam->height;
-    c->have_camera = true;
-    const size_t need = ptk::sched_bytes(c->camera);
+    ptd::Camera next{};
+    next.llc = ptd::f3{cam->lower_left_corner[0], cam->lower_left_corner[1], cam->lower_left_corner[2]};
+    next.origin = ptd::f3{cam->origin[0], cam->origin[1], cam->origin[2]};
+    next.horizontal = ptd::f3{cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]};
+    next.vertical = ptd::f3{cam->vertical[0], cam->vertical[1], cam->vertical[2]};
+    next.width = cam->width;
+    next.height = cam->height;
+    // the new frame's scratch first; camera and scratch are committed together, only on success
+    const size_t need = ptk::sched_bytes(next);
     if (need > c->sched_bytes) {
         PT_HIP(c, hipSetDevice(c->device));
-        PT_HIP(c, hipStreamSynchronize(c->stream));
+        int32_t *fresh = nullptr;
+        PT_HIP(c, hipMalloc((void **)&fresh, need));
+        // launches on caller streams (pt_render_device) may still be using the old scratch
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(c, PT_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e));
+        }
         if (c->last_sched == c->d_sched) c->last_sched = nullptr;
         if (c->d_sched) (void)hipFree(c->d_sched);
-        c->d_sched = nullptr;
-        c->sched_bytes = 0;
-        PT_HIP(c, hipMalloc((void **)&c->d_sched, need));
+        c->d_sched = fresh;
         c->sched_bytes = need;
     }
+    c->camera = next;
+    c->have_camera = true;
     return PT_OK;
 }
 
@@ -518,8 +532,14 @@ static int render_device_with(pt_context *c, int32_t samples, uint64_t seed, int
     (void)hipMemsetAsync(d_stats, 0, 128, st);
     rp.stats = d_stats;
 #endif
+    // One launch at a time per scratch: launches on one stream are ordered; a launch on ANOTHER stream
+    // while the previous one is still in flight would clear the tickets under it -- refused, not raced.
+    if (c->timed && c->last_sched == sched && c->last_stream != st && hipEventQuery(c->ev_stop) == hipErrorNotReady)
+        return fail(c, PT_ERR_INVALID, "the previous path-kernel launch of this context is still running on another stream: "
+                                       "its launches share one work-distribution scratch (one stream at a time)");
     PT_HIP(c, hipEventRecord(c->ev_start, st));
     c->last_sched = sched;
+    c->last_stream = st;
     PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
     PT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->timed = true;

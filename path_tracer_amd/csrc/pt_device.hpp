@@ -223,14 +223,19 @@ PTD Ray sample_ray(const Camera &c, int S, int px, int py, int s)
 
 // x / a from ra = RN(1/a) (correctly rounded reciprocal): a product and two fused residual
 // corrections instead of the 12-instruction IEEE expansion.  Correctly rounded for every x, a
-// whose quotient and residuals stay normal and whose a is not 2^24-1 ulps (all-ones mantissa):
-//   q0 = RN(x*ra) is within 2 ulp of x/a;  q1 = RN(q0 + r0*ra) is one of the two floats around
-//   x/a, so r1 = x - a*q1 is exact;  V = q1 + r1*ra = x/a + (x/a - q1)*eps, |eps| < 2^-24, and
-//   no rounding boundary m of the quotient can lie between V and x/a because
-//   |x/a - m| >= ulp(m)/2 / A with A = a's integer mantissa <= 2^24 - 2   (Markstein 1990).
-// Used only for the sample grid of trace_pixel, whose divisors are S-1, W and H (small integers)
-// and whose dividends are 0 or >= 1; pt_selftest_grid compares every grid coordinate of a frame
-// size with the IEEE divisions (tests/test_gpu_parity.py::test_sample_grid_division).
+// whose quotient and residuals stay normal:
+//   q0 = RN(x*ra) is within 2 ulp of x/a;  q1 = RN(q0 + r0*ra) is faithful (one of the two floats
+//   around x/a), so r1 = x - a*q1 is exact;  q2 = RN(q1 + r1*ra) is then RN(x/a) by Markstein's
+//   division theorem (1990; Cornea/Harrison/Tang, "Scientific Computing on Itanium", Thm 8.3), whose
+//   only hypotheses are "q1 faithful" and "ra = RN(1/a)" -- it holds for EVERY mantissa of a,
+//   including the all-ones one (2^24 - 1): that mantissa is the exception of the theorem that
+//   REFINES A RECIPROCAL, which is not used here -- ra comes from rcp_core, whose result is checked
+//   against 1/a for all 2^32 inputs (pt_selftest_unary).
+// Two users: the sample grid of trace_pixel, whose divisors are S-1, W and H (pt_selftest_grid
+// compares every grid coordinate of a frame size with the IEEE divisions), and Sphere::trace's
+// divisions by a = dot(d, d) for REGULAR rays (regular_ray below), where a is about 1 - 2^-24 --
+// the all-ones mantissa -- for most normalised directions: pt_selftest_division pins that mantissa
+// in a third of its pairs (mode 2), over all exponents of the class (tests/test_gpu_parity.py::test_reciprocal_division).
 PTD float div_by(float x, float a, float ra)
 {
     float q = x * ra;

@@ -46,6 +46,7 @@ struct Builder {
     std::vector<Box> suffix;     // scratch: suffix[i] = join(items[i..end)) of the current range
     pt_bvh_node *out;
     int32_t next = 0;
+    bool degenerate = false;     // a range whose every candidate split costs NaN: the reference panics (bvh.rs:19)
 
     // BvhNode::construct (bvh.rs:13-91) emitting DFS pre-order nodes directly.
     // The reference recomputes both side boxes for every candidate split
@@ -86,9 +87,14 @@ struct Builder {
             const float cost = cl + cr;
             if (cost < lowest) { best = i; lowest = cost; }
         }
-        if (best == 0) best = n / 2;   // reference panics here (bvh.rs:19): degenerate zero-volume input
+        // No candidate beat f32::MAX: every cost is NaN (zero-volume or non-finite bounds).  The
+        // reference recurses into an empty left range and panics (bvh.rs:19); no tree is invented
+        // here either -- the build is abandoned and pt_bvh_build returns PT_ERR_INVALID.
+        if (best == 0) { degenerate = true; return whole; }
         const Box l = construct(lo, lo + best);                                  // bvh.rs:82-85
+        if (degenerate) return whole;
         const Box r = construct(lo + best, hi);
+        if (degenerate) return whole;
         const Box bounds = join(l, r);                                           // bvh.rs:86
         emit(me, bounds, next, -1);
         return bounds;
@@ -121,13 +127,19 @@ int32_t pt_bvh_build(const pt_sphere *spheres, int32_t n_spheres, pt_bvh_node *o
     if (!spheres || !out || n_spheres < 1) return PT_ERR_INVALID;
     const int64_t need = 2ll * n_spheres - 1;
     if (capacity < need) return PT_ERR_LIMIT;
-    Builder b;
-    b.items.resize((size_t)n_spheres);
-    b.suffix.resize((size_t)n_spheres);
-    b.out = out;
-    for (int32_t i = 0; i < n_spheres; i++) { b.items[i].prim = i; b.items[i].box = sphere_box(spheres[i]); }
-    b.construct(0, n_spheres);
-    return b.next;
+    // nothing may unwind across the C ABI: resize and std::stable_sort (which takes a buffer) can throw
+    try {
+        Builder b;
+        b.items.resize((size_t)n_spheres);
+        b.suffix.resize((size_t)n_spheres);
+        b.out = out;
+        for (int32_t i = 0; i < n_spheres; i++) { b.items[i].prim = i; b.items[i].box = sphere_box(spheres[i]); }
+        b.construct(0, n_spheres);
+        if (b.degenerate) return PT_ERR_INVALID;
+        return b.next;
+    } catch (...) {
+        return PT_ERR_LIMIT;   // out of host memory
+    }
 }
 
 int pt_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_degrees, int32_t width,

@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256) void grid_selftest_kernel(unsigned long long *
 // pt_selftest_division: 64 operand pairs (x, a) per lane for Sphere::trace's division x / a through
 // ra = RN(1/a) (pt_device.hpp div_by, regular_ray): a over the whole REGULAR range [2^-32, 2^32]
 // with mantissas biased to the ends of the binade; x random (mode 0) or built so that x / a lies
-// within two ulps of a rounding midpoint (mode 1), the case a division algorithm gets wrong first.
+// within two ulps of a rounding midpoint (mode 1), the case a division algorithm gets wrong first;
+// mode 2 pins a's mantissa to all ones (dot(d, d) of a normalised direction is 1 - 2^-24 more often than not).
 __device__ __forceinline__ uint64_t selftest_mix(uint64_t z)
 {
     z += 0x9E3779B97F4A7C15ull;
@@ -509,12 +510,13 @@ __global__ __launch_bounds__(256) void division_selftest_kernel(unsigned long lo
         uint32_t am = (uint32_t)h & 0x7fffffu;
         if ((h >> 60) == 0) am = 0x7fffffu - (am & 0xffu);
         if ((h >> 60) == 1) am = am & 0xffu;
+        if (mode == 2) am = 0x7fffffu;                                           // a = (2 - 2^-23) 2^e: dot(d, d) of a normalised d
         int ae = (int)((h >> 23) % 65) - 32;
         if (ae == 32) am = 0;                                                    // the range ends AT 2^32
         const float a = __uint_as_float(((uint32_t)(ae + 127) << 23) | am);
         const uint64_t g = selftest_mix(h);
         float x;
-        if (mode == 0) {
+        if (mode == 0 || (mode == 2 && (g >> 61) == 0)) {
             const uint32_t xm = (uint32_t)g & 0x7fffffu;
             const int xe = (int)((g >> 23) % 107) - 53;                          // |x| < 2^53 (regular_ray)
             x = __uint_as_float(((uint32_t)(g >> 63) << 31) | ((uint32_t)(xe + 127) << 23) | xm);
@@ -565,9 +567,10 @@ hipError_t static_sched(int device, int32_t **out, size_t *bytes)
 
 hipError_t launch_division_selftest(int log2_pairs, unsigned long long *d_count, hipStream_t stream)
 {
-    // 2^log2_pairs operand pairs, half of them random and half next to midpoints; 64 per lane
+    // 2^log2_pairs operand pairs in modes 0 (random x) and 1 (x / a next to a rounding midpoint), half each,
+    // and half as many again in mode 2: a's mantissa pinned to all ones (1/8 random x, 7/8 next to midpoints); 64 per lane
     const uint64_t lanes = (1ull << log2_pairs) / 64 / 2;
-    for (int mode = 0; mode < 2; mode++)
+    for (int mode = 0; mode < 3; mode++)
         for (uint64_t first = 0; first < lanes; first += (1ull << 28)) {
             const uint64_t n = lanes - first < (1ull << 28) ? lanes - first : (1ull << 28);
             hipLaunchKernelGGL(division_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_count,

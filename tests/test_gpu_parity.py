@@ -133,6 +133,31 @@ def test_error_codes(renderer):
     assert renderer.render(rt).shape == (16, 32, 3)        # the context survives the errors
 
 
+def test_second_stream_while_a_launch_is_running_is_refused(renderer, oracle):
+    """A context's launches share one work-distribution scratch (pt_amd.h): a launch on a second stream
+    while the previous one is still running is refused (PT_ERR_INVALID), never raced; once the first has
+    finished the second stream is fine, and the first launch's result is untouched."""
+    import path_tracer_amd as pt
+    torch = pytest.importorskip("torch")
+    rt = make_raytracer("rtow", 1280, 720, 16)                 # tens of milliseconds of kernel time
+    dev = torch.device("cuda", 0)
+    n = rt.width() * rt.height() * 3
+    a, b = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    buf_a = torch.zeros(n, dtype=torch.float32, device=dev)
+    buf_b = torch.zeros(n, dtype=torch.float32, device=dev)
+    renderer.bind(rt)
+    torch.cuda.synchronize()
+    renderer.render_device(rt, buf_a.data_ptr(), seed=5, stream=a.cuda_stream)
+    with pytest.raises(pt.PtError) as err:
+        renderer.render_device(rt, buf_b.data_ptr(), seed=5, stream=b.cuda_stream)
+    assert err.value.code == -1
+    a.synchronize()
+    renderer.render_device(rt, buf_b.data_ptr(), seed=5, stream=b.cuda_stream)
+    b.synchronize()
+    assert renderer.last_path_kernel_ms() > 0.0
+    assert same_bits(buf_a.cpu().numpy(), buf_b.cpu().numpy())
+
+
 def test_axis_aligned_rays_nan_and_inf_slabs(renderer, oracle):
     """Camera looking straight down -z with eye.x = eye.y = 0: the centre column / row of
     pixels get direction components that are EXACTLY zero (1/0 = inf), and spheres are placed

@@ -201,3 +201,21 @@ def test_cpp_host_png_writer_roundtrip(tmp_path):
     i = np.arange(301 * 97 * 3, dtype=np.uint64)
     want = (((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(13)).astype(np.uint8).reshape(97, 301, 3)
     assert img.shape == (97, 301, 3) and np.array_equal(img, want)
+
+
+def test_bvh_build_refuses_degenerate_bounds():
+    """bvh.rs:58-80 on zero-volume bounds: every candidate cost is NaN, the reference recurses into an
+    empty range and panics (bvh.rs:19).  pt_bvh_build returns PT_ERR_INVALID -- it does not invent a split."""
+    spheres = (_abi.PtSphere * 3)()
+    for i in range(3):
+        spheres[i] = _abi.PtSphere(1.0, 2.0, 3.0, 0.0, 0)          # three points: whole volume 0
+    nodes = (_abi.PtBvhNode * 5)()
+    assert pt.lib().pt_bvh_build(spheres, 3, nodes, 5) == -1       # PT_ERR_INVALID
+    # non-finite bounds likewise
+    spheres[1] = _abi.PtSphere(float("inf"), 0.0, 0.0, 1.0, 0)
+    assert pt.lib().pt_bvh_build(spheres, 3, nodes, 5) == -1
+    # and a regular input still builds
+    for i in range(3):
+        spheres[i] = _abi.PtSphere(float(i), 0.0, 0.0, 0.25, 0)
+    assert pt.lib().pt_bvh_build(spheres, 3, nodes, 5) == 5
+    assert pt.lib().pt_bvh_build(spheres, 3, nodes, 4) == -5       # PT_ERR_LIMIT: capacity
