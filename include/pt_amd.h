@@ -212,6 +212,39 @@ int pt_selftest_grid(pt_context *ctx, int32_t samples, uint64_t *mismatches);
  * exist); the proof is Markstein's theorem, this is its check.  Returns the number that differ. */
 int pt_selftest_division(pt_context *ctx, int32_t log2_pairs, uint64_t *mismatches);
 
+/* ---- several GPUs of one node ------------------------------------------------
+ * No counterpart in the reference (one process of shared-memory threads,
+ * src/parallel_renderer/mod.rs:88-145).  A group is ONE host process driving n GPUs: each holds the
+ * whole scene and renders a contiguous share of the samples x samples grid -- the index
+ * s = sx * samples + sy of src/raytracer.rs:77-81 is the unit that shards -- into a full-frame fp32
+ * radiance buffer; one RCCL reduce (ncclReduce, sum, fp32, W*H*3 values, root = devices[0]) over
+ * xGMI merges them on the render streams; the root resolves (raytracer.rs:92-93,119-121) and copies
+ * the image to the host.  Per GPU the sums are the reference's sequential sums over its share; the
+ * order in which the n shares are added is RCCL's: exact for n <= 2, rounding-level (<= n ulp of the
+ * sum) beyond.  A group is used from one host thread at a time. */
+typedef struct pt_group pt_group;
+int pt_group_create(const int32_t *devices, int32_t n_devices, pt_group **out);   /* ncclCommInitAll over the devices */
+void pt_group_destroy(pt_group *group);
+const char *pt_group_last_error(const pt_group *group);   /* group may be NULL: create failures */
+int32_t pt_group_size(const pt_group *group);
+/* the context of GPU `rank` of the group, borrowed (pt_query, pt_set_lanes_per_pixel, ...); NULL if out of range */
+pt_context *pt_group_context(pt_group *group, int32_t rank);
+/* pt_upload_scene / pt_set_camera on every GPU of the group (the BVH is built once, on the host) */
+int pt_group_upload_scene(pt_group *group, const pt_sphere *spheres, int32_t n_spheres,
+                          const pt_material *materials, int32_t n_materials,
+                          const pt_texture *textures, int32_t n_textures,
+                          const pt_bvh_node *nodes, int32_t n_nodes);
+int pt_group_set_camera(pt_group *group, const pt_camera *camera);
+/* pt_render of the full grid over the group.  Blocking.  rgb8 / radiance: host buffers as for
+ * pt_render (either may be NULL); radiance is the merged sum. */
+int pt_group_render(pt_group *group, int32_t samples, uint64_t seed, uint8_t *rgb8, float *radiance);
+/* Share of GPU `rank` of n: sample indices [*begin, *end), contiguous, sizes differ by at most one. */
+void pt_group_shard(int32_t samples, int32_t rank, int32_t n, int32_t *begin, int32_t *end);
+/* Timings of the last pt_group_render: kernel_ms[r] = GPU r's path kernel (HIP events on its stream),
+ * up to `capacity` entries; *reduce_ms = from the end of the root's path kernel to the end of the
+ * reduce on the root's stream (so it includes waiting for the slowest GPU).  Returns the group size. */
+int pt_group_timings(const pt_group *group, float *kernel_ms, int32_t capacity, float *reduce_ms);
+
 /* ---- host-side helpers (pure CPU, no GPU needed) ------------------------- */
 
 /* BvhNode::construct + pre-order flatten (src/scene/bvh.rs:13-91).  Returns the

@@ -7,12 +7,12 @@ path_tracer_amd/csrc).  This package is the thin host mirror of the reference's
 builder API used by the tests and the benchmark.  There is no CPU fallback.
 """
 from ._abi import LIB_PATH, PtError, lib
-from .renderer import ParallelRenderer, Raytracer, shard_range
+from .renderer import ParallelRenderer, Raytracer, RendererGroup, group_shard, shard_range
 from .scene import (REFERENCE_BOUNDS, RTOW_BOUNDS, Camera, Dielectric, Lambertian, Metal, PictureTexture, Scene,
                     SolidTexture, Sphere, random_scene, simple_scene)
 
 __all__ = [
-    "LIB_PATH", "PtError", "lib", "ParallelRenderer", "Raytracer", "shard_range", "REFERENCE_BOUNDS", "RTOW_BOUNDS",
+    "LIB_PATH", "PtError", "lib", "ParallelRenderer", "Raytracer", "RendererGroup", "group_shard", "shard_range", "REFERENCE_BOUNDS", "RTOW_BOUNDS",
     "Camera", "Dielectric", "Lambertian", "Metal", "PictureTexture", "Scene", "SolidTexture", "Sphere",
     "random_scene", "simple_scene",
 ]

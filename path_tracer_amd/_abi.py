@@ -70,6 +70,17 @@ SIGNATURES = {
     "pt_selftest_unary": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_selftest_grid": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_selftest_division": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "pt_group_create": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "pt_group_destroy": (None, [C.c_void_p]),
+    "pt_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "pt_group_size": (C.c_int32, [C.c_void_p]),
+    "pt_group_context": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "pt_group_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(PtSphere), C.c_int32, C.POINTER(PtMaterial), C.c_int32,
+                                        C.POINTER(PtTexture), C.c_int32, C.POINTER(PtBvhNode), C.c_int32]),
+    "pt_group_set_camera": (C.c_int, [C.c_void_p, C.POINTER(PtCamera)]),
+    "pt_group_render": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pt_group_shard": (None, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pt_group_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "pt_bvh_build": (C.c_int32, [C.POINTER(PtSphere), C.c_int32, C.POINTER(PtBvhNode), C.c_int32]),
     "pt_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                     C.c_int32, C.c_int32, C.POINTER(PtCamera)]),

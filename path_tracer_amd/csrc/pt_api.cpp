@@ -11,8 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/pt_amd.h"
-#include "pt_kernels.hpp"
+#include "pt_context.hpp"
 
 namespace {
 
@@ -27,42 +26,7 @@ constexpr int32_t kMaxLdsNodes = 1024;
 
 }  // namespace
 
-struct pt_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
-    std::string error;
-
-    // device scene
-    float4 *d_nodes = nullptr;
-    float4 *d_prims = nullptr;
-    ptd::Texture *d_textures = nullptr;
-    std::vector<uint8_t *> d_texels;
-    ptd::Scene scene{};
-    bool have_scene = false;
-
-    ptd::Camera camera{};
-    bool have_camera = false;
-
-    // frame-sized scratch for the host-buffer entry point pt_render
-    float *d_radiance = nullptr;
-    uint8_t *d_rgb8 = nullptr;
-    int32_t *d_hit_id = nullptr;
-    int64_t frame_pixels = 0;
-
-    int32_t lanes_override = 0;
-
-    int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
-    size_t sched_bytes = 0;
-    // the device's copy of the library's file-scope scratch array (pt_render_device_static), resolved in pt_create
-    int32_t *static_sched = nullptr;
-    size_t static_sched_bytes = 0;
-    int32_t *last_sched = nullptr;   // the scratch the most recent path-kernel launch used (its error word)
-    hipStream_t last_stream = nullptr;   // and the stream it went to
-};
-
-namespace {
+namespace ptapi {
 
 int fail(pt_context *ctx, int code, const char *fmt, ...)
 {
@@ -76,11 +40,44 @@ int fail(pt_context *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-#define PT_HIP(ctx, call)                                                                                   \
-    do {                                                                                                    \
-        hipError_t e_ = (call);                                                                             \
-        if (e_ != hipSuccess) return fail((ctx), PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
+}  // namespace ptapi
+
+using ptapi::fail;
+
+namespace {
+void free_frame(pt_context *c);
+}
+
+namespace ptapi {
+
+int ensure_frame(pt_context *c)
+{
+    const int64_t px = (int64_t)c->camera.width * c->camera.height;
+    if (px == c->frame_pixels) return PT_OK;
+    free_frame(c);
+    PT_HIP(c, hipMalloc((void **)&c->d_radiance, (size_t)px * 3 * sizeof(float)));
+    PT_HIP(c, hipMalloc((void **)&c->d_rgb8, (size_t)px * 3));
+    PT_HIP(c, hipMalloc((void **)&c->d_hit_id, (size_t)px * sizeof(int32_t)));
+    c->frame_pixels = px;
+    return PT_OK;
+}
+
+// the kernel's bounded dependency wait (pt_kernels.hip) reports here instead of hanging
+int check_kernel_error(pt_context *c)
+{
+    if (!c->last_sched) return PT_OK;
+    int32_t ctrl[2] = {0, 0};
+    PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
+    if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
+    if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
+    return PT_OK;
+}
+
+}  // namespace ptapi
+
+using ptapi::ensure_frame;
+
+namespace {
 
 void free_scene(pt_context *c)
 {
@@ -103,18 +100,6 @@ void free_frame(pt_context *c)
     c->d_rgb8 = nullptr;
     c->d_hit_id = nullptr;
     c->frame_pixels = 0;
-}
-
-int ensure_frame(pt_context *c)
-{
-    const int64_t px = (int64_t)c->camera.width * c->camera.height;
-    if (px == c->frame_pixels) return PT_OK;
-    free_frame(c);
-    PT_HIP(c, hipMalloc((void **)&c->d_radiance, (size_t)px * 3 * sizeof(float)));
-    PT_HIP(c, hipMalloc((void **)&c->d_rgb8, (size_t)px * 3));
-    PT_HIP(c, hipMalloc((void **)&c->d_hit_id, (size_t)px * sizeof(int32_t)));
-    c->frame_pixels = px;
-    return PT_OK;
 }
 
 int check_ready(pt_context *c, int32_t samples)
@@ -631,13 +616,7 @@ int pt_render(pt_context *c, int32_t samples, uint64_t seed, int32_t sample_begi
         PT_HIP(c, hipMemcpyAsync(hit_id, c->d_hit_id, px * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     }
     PT_HIP(c, hipStreamSynchronize(c->stream));
-    if (rgb8 || radiance) {
-        // the kernel's bounded dependency wait (pt_kernels.hip) reports here instead of hanging
-        int32_t ctrl[2] = {0, 0};
-        PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
-        if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
-        if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
-    }
+    if (rgb8 || radiance) return ptapi::check_kernel_error(c);
     return PT_OK;
 }
 
@@ -657,10 +636,8 @@ int pt_render_progress(pt_context *c, int32_t samples, uint64_t seed, int32_t pa
         rc = pt_render_device(c, samples, seed, begin, end, k > 0, c->d_radiance, nullptr);
         if (rc != PT_OK) return rc;
         PT_HIP(c, hipStreamSynchronize(c->stream));
-        int32_t ctrl[2] = {0, 0};
-        PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
-        if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
-        if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
+        rc = ptapi::check_kernel_error(c);
+        if (rc != PT_OK) return rc;
         if (progress && progress(user, end, total) != 0)
             return fail(c, PT_ERR_CANCELLED, "cancelled by the progress callback after %d of %d samples", end, total);
     }

@@ -1,0 +1,60 @@
+// pt_context.hpp -- the context behind include/pt_amd.h's opaque pt_context, shared by the
+// translation units that implement the C ABI (pt_api.cpp: one GPU; pt_group.cpp: several).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_kernels.hpp"
+
+struct pt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::string error;
+
+    // device scene
+    float4 *d_nodes = nullptr;
+    float4 *d_prims = nullptr;
+    ptd::Texture *d_textures = nullptr;
+    std::vector<uint8_t *> d_texels;
+    ptd::Scene scene{};
+    bool have_scene = false;
+
+    ptd::Camera camera{};
+    bool have_camera = false;
+
+    // frame-sized scratch for the host-buffer entry point pt_render
+    float *d_radiance = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    int32_t *d_hit_id = nullptr;
+    int64_t frame_pixels = 0;
+
+    int32_t lanes_override = 0;
+
+    int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
+    size_t sched_bytes = 0;
+    // the device's copy of the library's file-scope scratch array (pt_render_device_static), resolved in pt_create
+    int32_t *static_sched = nullptr;
+    size_t static_sched_bytes = 0;
+    int32_t *last_sched = nullptr;   // the scratch the most recent path-kernel launch used (its error word)
+    hipStream_t last_stream = nullptr;   // and the stream it went to
+};
+
+namespace ptapi {
+// records the message on the context (or for pt_last_error(NULL) when ctx is NULL) and returns `code`
+int fail(pt_context *ctx, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+// frame-sized device buffers of the context (radiance, rgb8, hit ids) for its current camera
+int ensure_frame(pt_context *c);
+// reads the error word the most recent path-kernel launch left (the launch must have completed)
+int check_kernel_error(pt_context *c);
+}  // namespace ptapi
+
+#define PT_HIP(ctx, call)                                                                                          \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess) return ptapi::fail((ctx), PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)

@@ -156,6 +156,91 @@ class ParallelRenderer:
         return int(n.value)
 
 
+class RendererGroup:
+    """Several GPUs of one node in ONE process (include/pt_amd.h, pt_group_*): the samples x samples grid
+    is shared out over the GPUs, one RCCL reduce merges the fp32 radiance buffers on the first GPU,
+    which resolves.  No counterpart in the reference (shared-memory threads only)."""
+
+    def __init__(self, devices):
+        devices = [int(d) for d in devices]
+        self._grp = C.c_void_p()
+        arr = (C.c_int32 * len(devices))(*devices)
+        rc = _abi.lib().pt_group_create(arr, len(devices), C.byref(self._grp))
+        if rc != _abi.PT_OK:
+            msg = _abi.lib().pt_group_last_error(None)
+            raise _abi.PtError(rc, msg.decode() if msg else "pt_group_create failed")
+        self.devices = devices
+        self._raytracer = None
+
+    @classmethod
+    def new(cls, devices):
+        return cls(devices)
+
+    def _check(self, rc):
+        if rc != _abi.PT_OK:
+            msg = _abi.lib().pt_group_last_error(self._grp)
+            raise _abi.PtError(rc, msg.decode() if msg else "unknown error")
+
+    def close(self):
+        if self._grp:
+            _abi.lib().pt_group_destroy(self._grp)
+            self._grp = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return _abi.lib().pt_group_size(self._grp)
+
+    def set_lanes_per_pixel(self, lanes):
+        for r in range(self.size()):
+            ctx = C.c_void_p(_abi.lib().pt_group_context(self._grp, r))
+            _abi.check(ctx, _abi.lib().pt_set_lanes_per_pixel(ctx, int(lanes)))
+
+    def bind(self, raytracer):
+        if self._raytracer is raytracer:
+            return
+        p = raytracer.packed
+        tex = p.texture_structs()
+        nodes = raytracer.nodes
+        self._check(_abi.lib().pt_group_upload_scene(
+            self._grp, p.spheres, p.n_spheres, p.materials, p.n_materials, tex, len(p.textures),
+            nodes, len(nodes) if nodes is not None else 0))
+        self._check(_abi.lib().pt_group_set_camera(self._grp, C.byref(raytracer.camera.pod)))
+        self._raytracer = raytracer
+
+    def render(self, raytracer, buffer=None, seed=0, radiance=False):
+        """The full frame over the group; returns ``buffer`` or ``(buffer, radiance)``."""
+        self.bind(raytracer)
+        w, h, s = raytracer.width(), raytracer.height(), raytracer.samples
+        if buffer is None:
+            buffer = np.zeros((h, w, 3), dtype=np.uint8)
+        if buffer.dtype != np.uint8 or buffer.size != w * h * 3 or not buffer.flags["C_CONTIGUOUS"]:
+            raise ValueError("buffer must be a C-contiguous uint8 array of %d x %d pixels" % (w, h))
+        rad = np.zeros((h, w, 3), dtype=np.float32) if radiance else None
+        self._check(_abi.lib().pt_group_render(self._grp, s, int(seed) & (2 ** 64 - 1), buffer.ctypes.data,
+                                               rad.ctypes.data if rad is not None else None))
+        return (buffer, rad) if radiance else buffer
+
+    def timings(self):
+        """({rank: path-kernel ms}, reduce ms) of the last render."""
+        n = self.size()
+        k = (C.c_float * n)()
+        red = C.c_float(-1.0)
+        _abi.lib().pt_group_timings(self._grp, k, n, C.byref(red))
+        return [float(x) for x in k], float(red.value)
+
+
+def group_shard(samples, rank, n):
+    """pt_group_shard: the share of GPU `rank` of `n` (equals distributed.shard_range)."""
+    b, e = C.c_int32(0), C.c_int32(0)
+    _abi.lib().pt_group_shard(int(samples), int(rank), int(n), C.byref(b), C.byref(e))
+    return int(b.value), int(e.value)
+
+
 class Raytracer:
     """raytracer.rs:29-44: camera + scene + samples; ``new`` builds the BVH
     (Scene::construct_bvh, scene/mod.rs:50-60) -- here with pt_bvh_build on the host,

@@ -133,6 +133,54 @@ def test_error_codes(renderer):
     assert renderer.render(rt).shape == (16, 32, 3)        # the context survives the errors
 
 
+def test_group_render_matches_oracle_shards(oracle):
+    """pt_group_render (ncclCommInitAll + ncclReduce inside the library): with one GPU the frame equals the
+    oracle's bit for bit; with two (when the box has them) it equals the sum of the oracle's two shard
+    renders bit for bit (a + b is commutative, so RCCL's order cannot matter)."""
+    import path_tracer_amd as pt
+    torch = pytest.importorskip("torch")
+    rt = make_raytracer("rtow", 160, 90, 6)
+    osc = oracle.OracleScene(rt.packed)
+    for n in (1, 2):
+        if torch.cuda.device_count() < n:
+            continue
+        group = pt.RendererGroup.new(range(n))
+        try:
+            group.set_lanes_per_pixel(1)
+            img, rad = group.render(rt, seed=RENDER_SEED, radiance=True)
+            total = None
+            for r in range(n):
+                part = osc.render(rt.camera.pod, 6, seed=RENDER_SEED, sample_range=pt.group_shard(6, r, n))["radiance"]
+                total = part if total is None else total + part
+            assert same_bits(rad, total)
+            assert np.array_equal(img, osc.resolve(total, 6))
+            k, red = group.timings()
+            assert len(k) == n and all(x > 0.0 for x in k) and red >= 0.0
+            img2 = group.render(rt, seed=RENDER_SEED)              # a second frame through the same communicators
+            assert np.array_equal(img2, img)
+        finally:
+            group.close()
+
+
+def test_stream_ordered_render_reduce_resolve_equals_render(renderer, oracle):
+    """The one-process-per-GPU step of bench.py with a single rank: render_device -> (reduce) -> resolve_device
+    -> D2H, all on ONE non-default torch stream, equals pt_render's image."""
+    torch = pytest.importorskip("torch")
+    rt = make_raytracer("simple", 320, 180, 4)
+    dev = torch.device("cuda", 0)
+    n = rt.width() * rt.height() * 3
+    accum = torch.zeros(n, dtype=torch.float32, device=dev)
+    rgb8 = torch.zeros(n, dtype=torch.uint8, device=dev)
+    host = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        renderer.render_device(rt, accum.data_ptr(), seed=9, stream=side.cuda_stream)
+        renderer.resolve_device(rt, accum.data_ptr(), rgb8.data_ptr(), stream=side.cuda_stream)
+        host.copy_(rgb8, non_blocking=True)
+    side.synchronize()
+    assert np.array_equal(host.numpy().reshape(rt.height(), rt.width(), 3), renderer.render(rt, seed=9))
+
+
 def test_second_stream_while_a_launch_is_running_is_refused(renderer, oracle):
     """A context's launches share one work-distribution scratch (pt_amd.h): a launch on a second stream
     while the previous one is still running is refused (PT_ERR_INVALID), never raced; once the first has

@@ -219,3 +219,28 @@ def test_bvh_build_refuses_degenerate_bounds():
         spheres[i] = _abi.PtSphere(float(i), 0.0, 0.0, 0.25, 0)
     assert pt.lib().pt_bvh_build(spheres, 3, nodes, 5) == 5
     assert pt.lib().pt_bvh_build(spheres, 3, nodes, 4) == -5       # PT_ERR_LIMIT: capacity
+
+
+def test_group_shard_partitions_the_grid():
+    """pt_group_shard (library) == distributed.shard_range (torch.distributed path): contiguous shares that
+    tile [0, S*S), sizes differing by at most one."""
+    for samples in (2, 3, 10, 16, 64):
+        for n in (1, 2, 3, 4, 7, 8):
+            if samples * samples < n:
+                continue
+            shares = [pt.group_shard(samples, r, n) for r in range(n)]
+            assert shares == [pt.shard_range(samples, r, n) for r in range(n)]
+            assert shares[0][0] == 0 and shares[-1][1] == samples * samples
+            assert all(shares[r][1] == shares[r + 1][0] for r in range(n - 1))
+            sizes = [e - b for b, e in shares]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_group_create_argument_errors():
+    lib = pt.lib()
+    out = C.c_void_p()
+    assert lib.pt_group_create(None, 1, C.byref(out)) == -1
+    two = (C.c_int32 * 2)(0, 0)
+    assert lib.pt_group_create(two, 2, C.byref(out)) == -1          # a device listed twice
+    assert b"twice" in lib.pt_group_last_error(None)
+    assert lib.pt_group_size(None) == 0 and not lib.pt_group_context(None, 0)
