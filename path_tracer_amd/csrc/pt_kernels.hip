@@ -266,7 +266,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
 #ifdef PT_STATS
     unsigned st_n[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};
     unsigned long long st_c[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
-#define PT_STAT(k, n) do { st_n[k] += 1; st_l[k] += (n); } while (0)
+    // The counters live in LANE 0's registers and are updated with v_readlane / v_writelane, which ignore
+    // exec: a plain `st_n[k] += 1` inside a step only counts the steps lane 0 itself takes part in (and then
+    // averages the lanes per step over those, a size-biased sample).
+    auto st_add = [](unsigned v, unsigned n) -> unsigned {
+        const unsigned sum = (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+        asm volatile("s_nop 4\n v_writelane_b32 %0, %1, 0\n s_nop 1" : "+v"(v) : "s"(sum));
+        return v;
+    };
+#define PT_STAT(k, n) do { st_n[k] = st_add(st_n[k], 1u); st_l[k] = st_add(st_l[k], (unsigned)(n)); } while (0)
 #define PT_TIME(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_c[k] += t_ - st_t; st_t = t_; } while (0)
 #else
 #define PT_STAT(k, n) do { } while (0)
