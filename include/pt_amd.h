@@ -212,6 +212,68 @@ int pt_selftest_grid(pt_context *ctx, int32_t samples, uint64_t *mismatches);
  * exist); the proof is Markstein's theorem, this is its check.  Returns the number that differ. */
 int pt_selftest_division(pt_context *ctx, int32_t log2_pairs, uint64_t *mismatches);
 
+/* ---- extension: Cornell-box primitives, lights, integrator options ----------------
+ * NOT in the reference: it has one primitive (Sphere, src/traceable/mod.rs:1-7), three
+ * materials with `scatter` only (src/material/mod.rs:17-19), a fixed 5-bounce cap and the sky
+ * gradient (src/raytracer.rs:48,67-70).  The extension follows the same trait shapes --
+ * Traceable::trace(ray, min_t, max_t) -> Option<HitRecord> (src/traceable/mod.rs:36-39),
+ * Material::scatter (+ an `emitted` term) -- with the semantics of the lineage the reference comes
+ * from ("Ray Tracing: The Next Week": axis-aligned rects with a flip flag, a box = six rects,
+ * translate / rotate-Y instances, a diffuse light).  DESIGN.md section 10 is the specification;
+ * the oracle for it is this repository's own restatement (oracle/pt_oracle.c + oracle/np_oracle_ext.py):
+ * no reference parity is possible for something the reference does not contain.
+ * Scenes uploaded through pt_upload_scene are untouched by any of this. */
+enum { PT_DIFFUSE_LIGHT = 3 };   /* pt_material.kind: scatter -> None, emitted = albedo (any value >= 0, e.g. 15) */
+enum { PT_PRIM_SPHERE = 0, PT_PRIM_RECT = 1 };
+/* One primitive; its id (hit-id AOV) is its index.  Sphere: v = {cx, cy, cz, radius, -}; transform
+ * must be -1.  Rect: the plane `axis` = k (axis 0: a yz-rect, 1: an xz-rect, 2: an xy-rect), spanning
+ * [a0, a1] x [b0, b1] on the two other axes in increasing axis order: v = {a0, a1, b0, b1, k}; its
+ * normal is the unit vector of `axis`, negated when flip != 0; transform = index of a pt_transform
+ * (Translate(RotateY(rect))) or -1. */
+typedef struct {
+    int32_t kind, material, transform, axis, flip;
+    float v[5];
+} pt_primitive;
+/* Translate(RotateY(object)): object space -> world is a rotation about y by theta, then + offset.
+ * sin / cos cross the ABI as values (the host's libm computes them, like Camera::new's tan). */
+typedef struct {
+    float offset[3];
+    float sin_theta, cos_theta;
+} pt_transform;
+/* trace_ray's constants as parameters.  Defaults = the reference: max_bounces 5 (MAX_TRACES,
+ * raytracer.rs:48), background_kind 0 = the sky gradient of raytracer.rs:67-68, rr_start -1 = no
+ * Russian roulette.  background_kind 1 = the constant colour `background`.  rr_start >= 0: after
+ * the scatter that completes bounce number b >= rr_start (b counts from 1), with q = the largest
+ * attenuation component, if q < 1 one more rng.rand() is drawn; the path ends unless rand < q, else
+ * attenuation /= q. */
+typedef struct {
+    int32_t max_bounces, background_kind;
+    float background[3];
+    int32_t rr_start;
+} pt_integrator;
+/* pt_upload_scene for a primitive list.  nodes: DFS pre-order tree over the primitives' world-space
+ * boxes as for pt_upload_scene (prim = primitive index), or NULL: built here (pt_bvh_build_ext).  A
+ * scene uploaded this way renders with the extension's kernel, whatever it contains. */
+int pt_upload_scene_ext(pt_context *ctx, const pt_primitive *prims, int32_t n_prims,
+                        const pt_material *materials, int32_t n_materials,
+                        const pt_texture *textures, int32_t n_textures,
+                        const pt_transform *transforms, int32_t n_transforms,
+                        const pt_bvh_node *nodes, int32_t n_nodes);
+/* Applies to scenes uploaded with pt_upload_scene_ext only (pt_upload_scene scenes always use the
+ * reference's constants); NULL restores the defaults. */
+int pt_set_integrator(pt_context *ctx, const pt_integrator *integrator);
+/* pt_bvh_build over primitives: the algorithm of src/scene/bvh.rs:13-91 on world-space boxes; a rect's
+ * box is padded by 0.0001 on its thin axis (zero volume would make every split cost NaN, bvh.rs:65),
+ * a transformed rect's box bounds the 8 rotated corners.  Returns 2 * n_prims - 1 or a negative status. */
+int32_t pt_bvh_build_ext(const pt_primitive *prims, int32_t n_prims, const pt_transform *transforms,
+                         int32_t n_transforms, pt_bvh_node *out, int32_t capacity);
+/* The Cornell box of "The Next Week": five walls, the light, two rotated boxes of six rects each
+ * (18 primitives, 4 materials, 2 transforms).  Returns the primitive count (18), or a negative status
+ * when a capacity (prims >= 18, materials >= 4, transforms >= 2) is too small.  sin / cos of the
+ * two box angles (-18 and 15 degrees) are the host libm's. */
+int32_t pt_gen_cornell_box(pt_primitive *prims, int32_t prim_capacity, pt_material *materials, int32_t material_capacity,
+                           pt_transform *transforms, int32_t transform_capacity);
+
 /* ---- several GPUs of one node ------------------------------------------------
  * No counterpart in the reference (one process of shared-memory threads,
  * src/parallel_renderer/mod.rs:88-145).  A group is ONE host process driving n GPUs: each holds the
@@ -235,6 +297,13 @@ int pt_group_upload_scene(pt_group *group, const pt_sphere *spheres, int32_t n_s
                           const pt_texture *textures, int32_t n_textures,
                           const pt_bvh_node *nodes, int32_t n_nodes);
 int pt_group_set_camera(pt_group *group, const pt_camera *camera);
+/* pt_upload_scene_ext / pt_set_integrator on every GPU of the group */
+int pt_group_upload_scene_ext(pt_group *group, const pt_primitive *prims, int32_t n_prims,
+                              const pt_material *materials, int32_t n_materials,
+                              const pt_texture *textures, int32_t n_textures,
+                              const pt_transform *transforms, int32_t n_transforms,
+                              const pt_bvh_node *nodes, int32_t n_nodes);
+int pt_group_set_integrator(pt_group *group, const pt_integrator *integrator);
 /* pt_render of the full grid over the group.  Blocking.  rgb8 / radiance: host buffers as for
  * pt_render (either may be NULL); radiance is the merged sum. */
 int pt_group_render(pt_group *group, int32_t samples, uint64_t seed, uint8_t *rgb8, float *radiance);

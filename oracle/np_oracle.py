@@ -296,7 +296,11 @@ class Scene:
         with np.errstate(**_err):
             p = o + d * t[:, None]                              # ray.rs:26-28
             nrm = normalized(p - self.c[prim])
-        m = self.mat[prim]
+        return self.scatter_at(d, p, nrm, self.mat[prim], rng)
+
+    def scatter_at(self, d, p, nrm, m, rng):
+        """Material::scatter (material/*.rs) for hits at p with normal nrm and material indices m."""
+        t = m
         kind = self.kind[m]
         n = len(t)
         ok = np.ones(n, bool)

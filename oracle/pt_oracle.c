@@ -62,13 +62,21 @@ typedef struct {
 /* pre-order dump of the reference's BvhNode tree (for cross-checking builders) */
 typedef struct { float bmin[3]; int32_t skip; float bmax[3]; int32_t prim; } ora_node;
 
-enum { ORA_LAMBERTIAN = 0, ORA_METAL = 1, ORA_DIELECTRIC = 2 };
+enum { ORA_LAMBERTIAN = 0, ORA_METAL = 1, ORA_DIELECTRIC = 2, ORA_DIFFUSE_LIGHT = 3 /* extension */ };
+
+/* EXTENSION (not in the reference): rects, Translate(RotateY(..)) instances,
+ * a diffuse light, trace_ray's constants as parameters.  Same POD layouts as include/pt_amd.h. */
+enum { ORA_PRIM_SPHERE = 0, ORA_PRIM_RECT = 1 };
+typedef struct { int32_t kind, material, transform, axis, flip; float v[5]; } ora_primitive;
+typedef struct { float offset[3]; float sin_theta, cos_theta; } ora_transform;
+typedef struct { int32_t max_bounces, background_kind; float background[3]; int32_t rr_start; } ora_integrator;
 
 /* event counters for the algorithmic-flop model of SURVEY.md section 8(d) */
 typedef struct {
     uint64_t paths, segments, aabb_tests, sphere_tests, sphere_near_hits,
         sphere_far_hits, lambert, lambert_textured, metal_scatter, metal_absorb,
-        dielectric_refract, dielectric_tir, rng_draws, sky_evals;
+        dielectric_refract, dielectric_tir, rng_draws, sky_evals,
+        /* extension */ rect_tests, rect_hits, rect_transformed, light_hits, rr_draws, rect_in_range, rect_hits_transformed;
 } ora_counters;
 
 typedef struct bvh_node {
@@ -84,6 +92,11 @@ typedef struct {
     ora_texture *textures; int n_textures;
     bvh_node *root;
     int n_nodes;
+    /* extension: set by ora_scene_create_ext only (ext == 0: the reference's path, untouched) */
+    int ext;
+    ora_primitive *prims; int n_prims;      /* spheres[i].material is filled for every primitive i */
+    ora_transform *xforms; int n_xforms;
+    ora_integrator integ;
 } ora_scene;
 
 /* ------------------------------------------------------- Vec3 (vec.rs) */
@@ -341,6 +354,7 @@ static inline void sphere_bbox(const ora_sphere *s, v3 *bmin, v3 *bmax)
     *bmax = vadd(c, vfill(s->radius));
 }
 
+/* hit_t: the HitRecord of traceable/mod.rs:11-17 + the primitive id */
 typedef struct { float t; v3 point, normal; int prim; } hit_t;
 
 /* sphere.rs:37-42 */
@@ -415,6 +429,76 @@ ORA_API void ora_texture_color(const uint8_t *rgb8, int32_t width, int32_t heigh
     out[0] = (float)px[0] / 255.0f;
     out[1] = (float)px[1] / 255.0f;
     out[2] = (float)px[2] / 255.0f;
+}
+
+/* ------------------------------------------------------- EXTENSION: rects and instances
+ * Not in the reference.  Shapes follow Traceable (traceable/mod.rs:36-39): trace(ray, min_t, max_t)
+ * -> Option<HitRecord>, bounding_box().  Semantics:
+ *   rect: plane `axis` = k over [a0,a1] x [b0,b1] on the other two axes (increasing axis order);
+ *         t = (k - o[axis]) / d[axis]; hit iff t < max_t && t > min_t (the comparison of
+ *         sphere.rs:57) and a0 <= a <= a1 and b0 <= b <= b1 with a = o[a] + d[a]*t; a NaN fails;
+ *         normal = the axis' unit vector, negated by `flip`; point = o + d*t;
+ *   Translate(RotateY(rect)): the ray goes to object space un-normalised (o - offset, then the
+ *         rotation by -theta on x/z), t is the same in both spaces; point and normal come back
+ *         by the rotation by +theta, the point then + offset. */
+static inline void rect_axes(int axis, int *ia, int *ib) { *ia = axis == 0 ? 1 : 0; *ib = axis == 2 ? 1 : 2; }
+static inline v3 rot_to_object(const ora_transform *x, v3 p)
+{
+    return V(x->cos_theta * p.x - x->sin_theta * p.z, p.y, x->sin_theta * p.x + x->cos_theta * p.z);
+}
+static inline v3 rot_to_world(const ora_transform *x, v3 p)
+{
+    return V(x->cos_theta * p.x + x->sin_theta * p.z, p.y, x->cos_theta * p.z - x->sin_theta * p.x);
+}
+static inline int rect_trace(const ora_scene *sc, const ora_primitive *p, int prim, const ray_t *ray, float min_t,
+                             float max_t, hit_t *h, ora_counters *cnt)
+{
+    v3 o = ray->o, d = ray->d;
+    const ora_transform *x = p->transform >= 0 ? &sc->xforms[p->transform] : NULL;
+    if (cnt) { cnt->rect_tests++; if (x) cnt->rect_transformed++; }
+    if (x) {
+        o = rot_to_object(x, vsub(o, V(x->offset[0], x->offset[1], x->offset[2])));
+        d = rot_to_object(x, d);
+    }
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    int ia, ib;
+    rect_axes(p->axis, &ia, &ib);
+    float t = (p->v[4] - oo[p->axis]) / dd[p->axis];
+    if (!(t < max_t && t > min_t)) return 0;
+    if (cnt) cnt->rect_in_range++;
+    float a = oo[ia] + dd[ia] * t, b = oo[ib] + dd[ib] * t;
+    if (!(a >= p->v[0] && a <= p->v[1] && b >= p->v[2] && b <= p->v[3])) return 0;
+    v3 pt = vadd(o, vmulf(d, t));
+    float nn[3] = {0.0f, 0.0f, 0.0f};
+    nn[p->axis] = p->flip ? -1.0f : 1.0f;
+    v3 n = V(nn[0], nn[1], nn[2]);
+    if (x) {
+        pt = vadd(rot_to_world(x, pt), V(x->offset[0], x->offset[1], x->offset[2]));
+        n = rot_to_world(x, n);
+    }
+    if (cnt) { cnt->rect_hits++; if (x) cnt->rect_hits_transformed++; }
+    h->t = t; h->point = pt; h->normal = n; h->prim = prim;
+    return 1;
+}
+/* bounding_box(): the rect padded by 0.0001 on its thin axis; a transformed rect: the box of its
+ * 8 rotated corners, then + offset */
+static inline void rect_bbox(const ora_scene *sc, const ora_primitive *p, v3 *bmin, v3 *bmax)
+{
+    float lo[3], hi[3];
+    int ia, ib;
+    rect_axes(p->axis, &ia, &ib);
+    lo[p->axis] = p->v[4] - 0.0001f; hi[p->axis] = p->v[4] + 0.0001f;
+    lo[ia] = p->v[0]; hi[ia] = p->v[1];
+    lo[ib] = p->v[2]; hi[ib] = p->v[3];
+    if (p->transform < 0) { *bmin = V(lo[0], lo[1], lo[2]); *bmax = V(hi[0], hi[1], hi[2]); return; }
+    const ora_transform *x = &sc->xforms[p->transform];
+    for (int c = 0; c < 8; c++) {
+        v3 w = rot_to_world(x, V((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]));
+        if (c == 0) { *bmin = w; *bmax = w; }
+        else { *bmin = vmin(w, *bmin); *bmax = vmax(w, *bmax); }
+    }
+    *bmin = vadd(*bmin, V(x->offset[0], x->offset[1], x->offset[2]));
+    *bmax = vadd(*bmax, V(x->offset[0], x->offset[1], x->offset[2]));
 }
 
 /* ------------------------------------------------------- BVH (scene/bvh.rs) */
@@ -505,7 +589,9 @@ static int bvh_trace(const ora_scene *sc, const bvh_node *n, const ray_t *ray, v
                      float max_t, hit_t *h, ora_counters *cnt)
 {
     if (n->is_leaf) {
-        int r = sphere_trace(&sc->spheres[n->prim], n->prim, ray, min_t, max_t, h, cnt);
+        int r = (sc->ext && sc->prims[n->prim].kind == ORA_PRIM_RECT)
+                    ? rect_trace(sc, &sc->prims[n->prim], n->prim, ray, min_t, max_t, h, cnt)   /* extension */
+                    : sphere_trace(&sc->spheres[n->prim], n->prim, ray, min_t, max_t, h, cnt);
         ev(r ? 'X' : 'L');
         return r;
     }
@@ -545,6 +631,8 @@ static int scatter(const ora_scene *sc, const ray_t *ray, const hit_t *h, rng_t 
 {
     const ora_material *m = &sc->materials[sc->spheres[h->prim].material];
     switch (m->kind) {
+    case ORA_DIFFUSE_LIGHT:                                 /* extension: a light does not scatter */
+        return 0;
     case ORA_LAMBERTIAN: {                                  /* lambertian.rs:32-45 */
         v3 target = vadd(vadd(h->point, h->normal), random_in_unit_sphere(rng));
         if (m->texture >= 0) { *att = sphere_uv_color(sc, m, h); if (cnt) cnt->lambert_textured++; }
@@ -657,6 +745,50 @@ static v3 trace_ray(const ora_scene *sc, ray_t ray, rng_t *rng, ora_counters *cn
     return vmul(color, attenuation);
 }
 
+/* EXTENSION: trace_ray with an emitted term and its constants as parameters (ora_integrator).  With the
+ * defaults (5 bounces, sky, no roulette) and no light in the scene it returns, bit for bit, what
+ * trace_ray returns: radiance stays +0 and 0 + x == x. */
+static v3 trace_ray_ext(const ora_scene *sc, ray_t ray, rng_t *rng, ora_counters *cnt)
+{
+    const ora_integrator *I = &sc->integ;
+    v3 attenuation = vfill(1.0f), radiance = vfill(0.0f);
+    if (cnt) cnt->paths++;
+    for (int i = 0; i < I->max_bounces; i++) {
+        hit_t h;
+        if (cnt) cnt->segments++;
+        if (!scene_trace(sc, &ray, &h, cnt)) break;
+        ev('H');
+        const ora_material *m = &sc->materials[sc->spheres[h.prim].material];
+        if (m->kind == ORA_DIFFUSE_LIGHT) {                 /* emitted(): the light's colour, whatever the side */
+            radiance = vadd(radiance, vmul(V(m->albedo[0], m->albedo[1], m->albedo[2]), attenuation));
+            if (cnt) cnt->light_hits++;
+        }
+        v3 att; ray_t nr;
+        if (!scatter(sc, &ray, &h, rng, &att, &nr, cnt)) { ev('E'); return radiance; }
+        attenuation = vmul(attenuation, att);
+        ray = nr;
+        if (I->rr_start >= 0 && i + 1 >= I->rr_start) {     /* Russian roulette on the largest component */
+            float q = rust_max(attenuation.x, rust_max(attenuation.y, attenuation.z));
+            if (q < 1.0f) {
+                if (cnt) cnt->rr_draws++;
+                float r = rnd(rng);
+                if (!(r < q)) { ev('E'); return radiance; }
+                attenuation = vdivf(attenuation, q);
+            }
+        }
+    }
+    ev('E');
+    if (cnt) cnt->sky_evals++;
+    v3 color;
+    if (I->background_kind == 0) {                          /* raytracer.rs:67-68 */
+        float t = 0.5f * (ray.d.y + 1.0f);
+        color = vadd(vmulf(V(1.0f, 1.0f, 1.0f), 1.0f - t), vmulf(V(0.5f, 0.7f, 1.0f), t));
+    } else {
+        color = V(I->background[0], I->background[1], I->background[2]);
+    }
+    return vadd(radiance, vmul(color, attenuation));
+}
+
 /* the sample grid of raytracer.rs:77-86; s = sx * S + sy (sx outer, sy inner) */
 static inline ray_t sample_ray(const ora_camera *cam, int S, int px, int py, int s)
 {
@@ -682,7 +814,8 @@ static v3 trace_pixel_sum(const ora_scene *sc, const ora_camera *cam, int S, uin
     v3 part = vfill(0.0f);
     for (int s = s0; s < s1; s++) {
         rng_t rng = {ora_path_stream(seed, pixel, (uint32_t)s), cnt};
-        v3 c = trace_ray(sc, sample_ray(cam, S, px, py, s), &rng, cnt);
+        v3 c = sc->ext ? trace_ray_ext(sc, sample_ray(cam, S, px, py, s), &rng, cnt)
+                       : trace_ray(sc, sample_ray(cam, S, px, py, s), &rng, cnt);
         if (chunk > 0) {
             part = vadd(part, c);
             if ((s - s0 + 1) % chunk == 0 || s + 1 == s1) { total = vadd(total, part); part = vfill(0.0f); }
@@ -708,10 +841,10 @@ ORA_API void ora_resolve(const float *radiance_sum, int64_t n_pixels, int32_t sa
 
 /* ------------------------------------------------------- scene objects */
 
-ORA_API ora_scene *ora_scene_create(const ora_sphere *spheres, int32_t n_spheres, const ora_material *materials,
-                                    int32_t n_materials, const ora_texture *textures, int32_t n_textures)
+/* copies of the caller's arrays; no tree yet */
+static ora_scene *scene_alloc(const ora_sphere *spheres, int32_t n_spheres, const ora_material *materials,
+                              int32_t n_materials, const ora_texture *textures, int32_t n_textures)
 {
-    if (n_spheres < 1) return NULL;
     ora_scene *sc = (ora_scene *)calloc(1, sizeof *sc);
     sc->n_spheres = n_spheres; sc->n_materials = n_materials; sc->n_textures = n_textures;
     sc->spheres = (ora_sphere *)malloc((size_t)n_spheres * sizeof *spheres);
@@ -727,6 +860,13 @@ ORA_API ora_scene *ora_scene_create(const ora_sphere *spheres, int32_t n_spheres
         sc->textures[i].height = textures[i].height;
         sc->textures[i].rgb8 = copy;
     }
+    return sc;
+}
+ORA_API ora_scene *ora_scene_create(const ora_sphere *spheres, int32_t n_spheres, const ora_material *materials,
+                                    int32_t n_materials, const ora_texture *textures, int32_t n_textures)
+{
+    if (n_spheres < 1) return NULL;
+    ora_scene *sc = scene_alloc(spheres, n_spheres, materials, n_materials, textures, n_textures);
     build_item *items = (build_item *)malloc((size_t)n_spheres * sizeof *items);
     build_item *tmp = (build_item *)malloc((size_t)n_spheres * sizeof *tmp);
     for (int i = 0; i < n_spheres; i++) {                   /* scene/mod.rs:46-48: insertion order */
@@ -737,9 +877,53 @@ ORA_API ora_scene *ora_scene_create(const ora_sphere *spheres, int32_t n_spheres
     free(items); free(tmp);
     return sc;
 }
+/* EXTENSION: a scene over a primitive list (spheres, rects with optional instances); trace_ray_ext is its
+ * integrator (defaults = the reference's constants until ora_set_integrator). */
+ORA_API ora_scene *ora_scene_create_ext(const ora_primitive *prims, int32_t n_prims, const ora_material *materials,
+                                        int32_t n_materials, const ora_texture *textures, int32_t n_textures,
+                                        const ora_transform *xforms, int32_t n_xforms)
+{
+    if (n_prims < 1) return NULL;
+    ora_sphere *spheres = (ora_sphere *)calloc((size_t)n_prims, sizeof *spheres);
+    for (int i = 0; i < n_prims; i++) {
+        if (prims[i].kind == ORA_PRIM_SPHERE) {
+            ora_sphere s = {prims[i].v[0], prims[i].v[1], prims[i].v[2], prims[i].v[3], prims[i].material};
+            spheres[i] = s;
+        } else {
+            spheres[i].material = prims[i].material;
+        }
+    }
+    ora_scene *sc = scene_alloc(spheres, n_prims, materials, n_materials, textures, n_textures);
+    free(spheres);
+    sc->ext = 1;
+    sc->n_prims = n_prims; sc->n_xforms = n_xforms;
+    sc->prims = (ora_primitive *)malloc((size_t)n_prims * sizeof *prims);
+    memcpy(sc->prims, prims, (size_t)n_prims * sizeof *prims);
+    sc->xforms = (ora_transform *)calloc((size_t)(n_xforms > 0 ? n_xforms : 1), sizeof *xforms);
+    if (n_xforms > 0) memcpy(sc->xforms, xforms, (size_t)n_xforms * sizeof *xforms);
+    ora_integrator dflt = {5, 0, {0.0f, 0.0f, 0.0f}, -1};    /* raytracer.rs:48,67-68 */
+    sc->integ = dflt;
+    build_item *items = (build_item *)malloc((size_t)n_prims * sizeof *items);
+    build_item *tmp = (build_item *)malloc((size_t)n_prims * sizeof *tmp);
+    for (int i = 0; i < n_prims; i++) {
+        items[i].prim = i;
+        if (prims[i].kind == ORA_PRIM_RECT) rect_bbox(sc, &prims[i], &items[i].bmin, &items[i].bmax);
+        else sphere_bbox(&sc->spheres[i], &items[i].bmin, &items[i].bmax);
+    }
+    sc->root = bvh_construct(items, tmp, n_prims, &sc->n_nodes);
+    free(items); free(tmp);
+    return sc;
+}
+ORA_API int ora_set_integrator(ora_scene *sc, const ora_integrator *integ)
+{
+    if (!sc || !sc->ext || !integ || integ->max_bounces < 1) return -1;
+    sc->integ = *integ;
+    return 0;
+}
 ORA_API void ora_scene_destroy(ora_scene *sc)
 {
     if (!sc) return;
+    free(sc->prims); free(sc->xforms);
     bvh_free(sc->root);
     for (int i = 0; i < sc->n_textures; i++) free((void *)sc->textures[i].rgb8);
     free(sc->textures); free(sc->materials); free(sc->spheres); free(sc);
@@ -858,7 +1042,8 @@ ORA_API void ora_trace_path(const ora_scene *sc, const ora_camera *cam, int32_t 
 {
     uint32_t pixel = (uint32_t)(py * cam->width + px);
     rng_t rng = {ora_path_stream(seed, pixel, (uint32_t)s), NULL};
-    v3 c = trace_ray(sc, sample_ray(cam, samples, px, py, s), &rng, NULL);
+    v3 c = sc->ext ? trace_ray_ext(sc, sample_ray(cam, samples, px, py, s), &rng, NULL)
+                   : trace_ray(sc, sample_ray(cam, samples, px, py, s), &rng, NULL);
     out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
 }
 

@@ -8,11 +8,14 @@ builder API used by the tests and the benchmark.  There is no CPU fallback.
 """
 from ._abi import LIB_PATH, PtError, lib
 from .renderer import ParallelRenderer, Raytracer, RendererGroup, group_shard, shard_range
-from .scene import (REFERENCE_BOUNDS, RTOW_BOUNDS, Camera, Dielectric, Lambertian, Metal, PictureTexture, Scene,
-                    SolidTexture, Sphere, random_scene, simple_scene)
+from .scene import (CORNELL_CAMERA, REFERENCE_BOUNDS, RTOW_BOUNDS, Camera, Dielectric, DiffuseLight, Integrator, Lambertian,
+                    Metal, PictureTexture, Rect, Scene, SolidTexture, Sphere, Transform, box_rects, cornell_box,
+                    random_scene, simple_scene)
 
 __all__ = [
     "LIB_PATH", "PtError", "lib", "ParallelRenderer", "Raytracer", "RendererGroup", "group_shard", "shard_range", "REFERENCE_BOUNDS", "RTOW_BOUNDS",
     "Camera", "Dielectric", "Lambertian", "Metal", "PictureTexture", "Scene", "SolidTexture", "Sphere",
     "random_scene", "simple_scene",
+    # extension (not in the reference): Cornell-box primitives, lights, integrator options
+    "CORNELL_CAMERA", "DiffuseLight", "Integrator", "Rect", "Transform", "box_rects", "cornell_box",
 ]

@@ -15,6 +15,8 @@ PT_OK = 0
 PT_ERR_CANCELLED = -6
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32)   # pt_progress_fn
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
+PT_DIFFUSE_LIGHT = 3                       # extension (include/pt_amd.h)
+PT_PRIM_SPHERE, PT_PRIM_RECT = 0, 1
 
 
 class PtSphere(C.Structure):
@@ -37,6 +39,20 @@ class PtCamera(C.Structure):
 
 class PtBvhNode(C.Structure):
     _fields_ = [("bmin", C.c_float * 3), ("skip", C.c_int32), ("bmax", C.c_float * 3), ("prim", C.c_int32)]
+
+
+class PtPrimitive(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("transform", C.c_int32), ("axis", C.c_int32),
+                ("flip", C.c_int32), ("v", C.c_float * 5)]
+
+
+class PtTransform(C.Structure):
+    _fields_ = [("offset", C.c_float * 3), ("sin_theta", C.c_float), ("cos_theta", C.c_float)]
+
+
+class PtIntegrator(C.Structure):
+    _fields_ = [("max_bounces", C.c_int32), ("background_kind", C.c_int32), ("background", C.c_float * 3),
+                ("rr_start", C.c_int32)]
 
 
 class PtDeviceInfo(C.Structure):
@@ -70,6 +86,18 @@ SIGNATURES = {
     "pt_selftest_unary": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_selftest_grid": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_selftest_division": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "pt_upload_scene_ext": (C.c_int, [C.c_void_p, C.POINTER(PtPrimitive), C.c_int32, C.POINTER(PtMaterial), C.c_int32,
+                                      C.POINTER(PtTexture), C.c_int32, C.POINTER(PtTransform), C.c_int32,
+                                      C.POINTER(PtBvhNode), C.c_int32]),
+    "pt_set_integrator": (C.c_int, [C.c_void_p, C.POINTER(PtIntegrator)]),
+    "pt_bvh_build_ext": (C.c_int32, [C.POINTER(PtPrimitive), C.c_int32, C.POINTER(PtTransform), C.c_int32,
+                                     C.POINTER(PtBvhNode), C.c_int32]),
+    "pt_gen_cornell_box": (C.c_int32, [C.POINTER(PtPrimitive), C.c_int32, C.POINTER(PtMaterial), C.c_int32,
+                                       C.POINTER(PtTransform), C.c_int32]),
+    "pt_group_upload_scene_ext": (C.c_int, [C.c_void_p, C.POINTER(PtPrimitive), C.c_int32, C.POINTER(PtMaterial), C.c_int32,
+                                            C.POINTER(PtTexture), C.c_int32, C.POINTER(PtTransform), C.c_int32,
+                                            C.POINTER(PtBvhNode), C.c_int32]),
+    "pt_group_set_integrator": (C.c_int, [C.c_void_p, C.POINTER(PtIntegrator)]),
     "pt_group_create": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     "pt_group_destroy": (None, [C.c_void_p]),
     "pt_group_last_error": (C.c_char_p, [C.c_void_p]),

@@ -84,8 +84,9 @@ void free_scene(pt_context *c)
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_textures) (void)hipFree(c->d_textures);
+    if (c->d_xforms) (void)hipFree(c->d_xforms);
     for (uint8_t *p : c->d_texels) (void)hipFree(p);
-    c->d_nodes = c->d_prims = nullptr;
+    c->d_nodes = c->d_prims = c->d_xforms = nullptr;
     c->d_textures = nullptr;
     c->d_texels.clear();
     c->have_scene = false;
@@ -200,53 +201,54 @@ int pt_query(const pt_context *c, pt_device_info *out)
     return PT_OK;
 }
 
-int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, const pt_material *materials,
-                    int32_t n_materials, const pt_texture *textures, int32_t n_textures, const pt_bvh_node *nodes,
-                    int32_t n_nodes)
+// pt_upload_scene / pt_upload_scene_ext: validation of the primitive list, the tree and the materials,
+// the device layout, the H2D copies.  `ext` selects the extension's kernel instantiation for the scene.
+static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_prims, const pt_material *materials,
+                         int32_t n_materials, const pt_texture *textures, int32_t n_textures, const pt_transform *xforms,
+                         int32_t n_xforms, const pt_bvh_node *nodes, int32_t n_nodes, bool ext)
 {
-    if (!c) return PT_ERR_INVALID;
-    if (!spheres || n_spheres < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one sphere (bvh.rs:19)");
     if (!materials || n_materials < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one material");
     if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, PT_ERR_INVALID, "bad texture array");
     // node codes are byte offsets (16 * slot) in an int32 with the sign bit as the Leaf flag, and the
-    // buffer resource's size is 16 * n_nodes: 2 * n_spheres - 1 nodes must stay below 2^(31 - PT_CODE_SHIFT)
-    if (n_spheres > (1 << (30 - PT_CODE_SHIFT)))
-        return fail(c, PT_ERR_LIMIT, "too many spheres (%d): the node encoding holds at most %d", n_spheres, 1 << (30 - PT_CODE_SHIFT));
-    for (int32_t i = 0; i < n_spheres; i++)
-        if (spheres[i].material < 0 || spheres[i].material >= n_materials)
-            return fail(c, PT_ERR_INVALID, "sphere %d: material index %d out of range [0, %d)", i, spheres[i].material, n_materials);
+    // buffer resource's size is 16 * n_nodes: 2 * n_prims - 1 nodes must stay below 2^(31 - PT_CODE_SHIFT)
+    if (n_prims > (1 << (30 - PT_CODE_SHIFT)))
+        return fail(c, PT_ERR_LIMIT, "too many primitives (%d): the node encoding holds at most %d", n_prims, 1 << (30 - PT_CODE_SHIFT));
     for (int32_t i = 0; i < n_materials; i++) {
         const pt_material &m = materials[i];
-        if (m.kind < PT_LAMBERTIAN || m.kind > PT_DIELECTRIC) return fail(c, PT_ERR_INVALID, "material %d: unknown kind %d", i, m.kind);
+        if (m.kind < PT_LAMBERTIAN || m.kind > (ext ? PT_DIFFUSE_LIGHT : PT_DIELECTRIC))
+            return fail(c, PT_ERR_INVALID, "material %d: unknown kind %d", i, m.kind);
         if (m.kind == PT_LAMBERTIAN && (m.texture < -1 || m.texture >= n_textures))
             return fail(c, PT_ERR_INVALID, "material %d: texture index %d not -1 or in [0, %d)", i, m.texture, n_textures);
+    }
+    for (int32_t i = 0; i < n_prims; i++) {
+        const pt_primitive &p = prims[i];
+        if (p.material < 0 || p.material >= n_materials)
+            return fail(c, PT_ERR_INVALID, "primitive %d: material index %d out of range [0, %d)", i, p.material, n_materials);
+        if (p.kind == PT_PRIM_RECT) {
+            if (!ext) return fail(c, PT_ERR_INVALID, "primitive %d: rects need pt_upload_scene_ext", i);
+            if (p.axis < 0 || p.axis > 2) return fail(c, PT_ERR_INVALID, "primitive %d: rect axis %d not 0, 1 or 2", i, p.axis);
+            if (p.transform < -1 || p.transform >= n_xforms)
+                return fail(c, PT_ERR_INVALID, "primitive %d: transform index %d not -1 or in [0, %d)", i, p.transform, n_xforms);
+            const pt_material &m = materials[p.material];
+            if (m.kind == PT_LAMBERTIAN && m.texture >= 0)
+                return fail(c, PT_ERR_INVALID, "primitive %d: a rect cannot carry a picture texture (sphere_uv is a sphere's, sphere.rs:6-18)", i);
+        } else if (p.kind == PT_PRIM_SPHERE) {
+            if (p.transform != -1) return fail(c, PT_ERR_INVALID, "primitive %d: a sphere takes no transform", i);
+        } else {
+            return fail(c, PT_ERR_INVALID, "primitive %d: unknown kind %d", i, p.kind);
+        }
     }
     for (int32_t i = 0; i < n_textures; i++)
         if (!textures[i].rgb8 || textures[i].width < 1 || textures[i].height < 1)
             return fail(c, PT_ERR_INVALID, "texture %d: empty image", i);
 
-    // BVH: caller's flattened tree, or build it here (bvh.rs:13-91)
-    std::vector<pt_bvh_node> built;
-    const int32_t expect = 2 * n_spheres - 1;
-    if (!nodes || n_nodes == 0) {
-        try {
-            built.resize((size_t)expect);
-        } catch (...) {
-            return fail(c, PT_ERR_INVALID, "out of host memory");
-        }
-        const int32_t got = pt_bvh_build(spheres, n_spheres, built.data(), expect);
-        if (got == PT_ERR_INVALID)
-            return fail(c, PT_ERR_INVALID, "BVH build: degenerate bounds (zero volume or non-finite) -- the reference panics here (bvh.rs:19)");
-        if (got != expect) return fail(c, PT_ERR_INVALID, "BVH build failed (%d)", got);
-        nodes = built.data();
-        n_nodes = got;
-    }
-    if (n_nodes != expect) return fail(c, PT_ERR_INVALID, "n_nodes = %d, a binary BVH over %d spheres has %d", n_nodes, n_spheres, expect);
+    const int32_t expect = 2 * n_prims - 1;
+    if (n_nodes != expect) return fail(c, PT_ERR_INVALID, "n_nodes = %d, a binary BVH over %d primitives has %d", n_nodes, n_prims, expect);
     // validate the walk the kernel will do: it follows skip links and prim ids unchecked
     for (int32_t i = 0; i < n_nodes; i++) {
         const pt_bvh_node &nd = nodes[i];
         if (nd.skip <= i || nd.skip > n_nodes) return fail(c, PT_ERR_INVALID, "node %d: skip %d not in (%d, %d]", i, nd.skip, i, n_nodes);
-        if (nd.prim >= n_spheres || nd.prim < -1) return fail(c, PT_ERR_INVALID, "node %d: prim %d out of range", i, nd.prim);
+        if (nd.prim >= n_prims || nd.prim < -1) return fail(c, PT_ERR_INVALID, "node %d: prim %d out of range", i, nd.prim);
         if (nd.prim >= 0 && nd.skip != i + 1) return fail(c, PT_ERR_INVALID, "node %d: a leaf's skip must be %d", i, i + 1);
         if (nd.prim < 0 && i + 1 >= n_nodes) return fail(c, PT_ERR_INVALID, "node %d: split without children", i);
     }
@@ -264,12 +266,13 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     // top of the tree -- visited by every ray -- is the prefix the path kernel keeps
     // in LDS; the walk order is unchanged, it follows the explicit next/skip codes.
     std::vector<int32_t> slot, order;
-    std::vector<float4> h_nodes, h_prims;
+    std::vector<float4> h_nodes, h_prims, h_xforms;
     try {
         slot.resize((size_t)n_nodes);
         order.reserve((size_t)n_nodes);
         h_nodes.resize(2 * (size_t)n_nodes);
-        h_prims.resize(2 * (size_t)n_spheres);
+        h_prims.resize(2 * (size_t)n_prims);
+        h_xforms.resize(2 * (size_t)(n_xforms > 0 ? n_xforms : 0));
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
@@ -304,6 +307,8 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
         if (i >= n_nodes) return n_nodes << PT_CODE_SHIFT;
         return nodes[i].prim >= 0 ? (int32_t)((uint32_t)(slot[i] << PT_CODE_SHIFT) | 0x80000000u) : (slot[i] << PT_CODE_SHIFT);
     };
+    // a rect's flags (pt_device.hpp rect_step): bit 0 = rect, bits 1-2 = axis, bit 3 = flip, bits 4.. = transform + 1
+    auto rect_flags = [](const pt_primitive &p) -> int32_t { return 1 | (p.axis << 1) | ((p.flip ? 1 : 0) << 3) | ((p.transform + 1) << 4); };
     float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_nodes;
     for (int32_t i = 0; i < n_nodes; i++) {
         const pt_bvh_node &nd = nodes[i];
@@ -314,9 +319,16 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
             a = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], 0.0f);
             b = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.0f);
             std::memcpy(&a.w, &skip, 4);
+        } else if (prims[nd.prim].kind == PT_PRIM_RECT) {
+            const pt_primitive &r = prims[nd.prim];
+            const int32_t flags = rect_flags(r);
+            a = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+            b = make_float4(r.v[4], 0.0f, 0.0f, 0.0f);
+            std::memcpy(&b.y, &flags, 4);
+            std::memcpy(&b.z, &nd.prim, 4);
         } else {
-            const pt_sphere &s = spheres[nd.prim];
-            a = make_float4(s.cx, s.cy, s.cz, s.radius * s.radius);   // sphere.rs:51: radius * radius, one fp32 multiply
+            const pt_primitive &s = prims[nd.prim];
+            a = make_float4(s.v[0], s.v[1], s.v[2], s.v[3] * s.v[3]);   // sphere.rs:51: radius * radius, one fp32 multiply
             b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             std::memcpy(&b.z, &nd.prim, 4);
         }
@@ -324,17 +336,28 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
         h_n0[slot[i]] = a;
         h_n1[slot[i]] = b;
     }
-    for (int32_t i = 0; i < n_spheres; i++) {
-        const pt_material &m = materials[spheres[i].material];
+    for (int32_t i = 0; i < n_prims; i++) {
+        const pt_primitive &p = prims[i];
+        const pt_material &m = materials[p.material];
         const int32_t tex = m.kind == PT_LAMBERTIAN ? m.texture : -1;
-        const int32_t tag = m.kind | ((tex + 1) << 2);
-        float4 a = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, 0.0f);
+        int32_t tag = m.kind | ((tex + 1) << 2);
+        float4 a = make_float4(p.v[0], p.v[1], p.v[2], 0.0f);
+        if (p.kind == PT_PRIM_RECT) {
+            const int32_t flags = rect_flags(p);
+            a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            std::memcpy(&a.x, &flags, 4);
+            tag |= 1 << 30;
+        }
         std::memcpy(&a.w, &tag, 4);
         h_prims[2 * (size_t)i] = a;
         h_prims[2 * (size_t)i + 1] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
         // a Dielectric has no albedo: the slots carry the two values its scatter derives from ref_idx
         // alone, math/mod.rs:37-38 and dielectric.rs:41, computed here with the same fp32 operations
         if (m.kind == PT_DIELECTRIC) h_prims[2 * (size_t)i + 1] = make_float4(ptd::schlick_r0(m.param), 1.0f / m.param, 0.0f, m.param);
+    }
+    for (int32_t i = 0; i < n_xforms; i++) {
+        h_xforms[2 * (size_t)i] = make_float4(xforms[i].offset[0], xforms[i].offset[1], xforms[i].offset[2], xforms[i].sin_theta);
+        h_xforms[2 * (size_t)i + 1] = make_float4(xforms[i].cos_theta, 0.0f, 0.0f, 0.0f);
     }
 
     PT_HIP(c, hipSetDevice(c->device));
@@ -344,6 +367,10 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     PT_HIP(c, hipMalloc((void **)&c->d_prims, h_prims.size() * sizeof(float4)));
     PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_prims, h_prims.data(), h_prims.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!h_xforms.empty()) {
+        PT_HIP(c, hipMalloc((void **)&c->d_xforms, h_xforms.size() * sizeof(float4)));
+        PT_HIP(c, hipMemcpy(c->d_xforms, h_xforms.data(), h_xforms.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     if (n_textures > 0) {
         std::vector<ptd::Texture> h_tex;
         try {
@@ -369,19 +396,88 @@ int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, 
     c->scene.n1 = c->d_nodes + n_nodes;
     c->scene.prims = c->d_prims;
     c->scene.textures = c->d_textures;
+    c->scene.xforms = c->d_xforms;
+    c->scene.ext = ext ? 1 : 0;
     c->scene.n_nodes = n_nodes;
-    c->scene.n_spheres = n_spheres;
+    c->scene.n_spheres = n_prims;
     c->scene.root_code = code_of(0);
     c->scene.lds_nodes = n_nodes < kMaxLdsNodes ? n_nodes : kMaxLdsNodes;
     // regular_ray (pt_device.hpp): the short division needs every sphere inside 2^32 (NaN fails the test)
     bool bounded = true;
-    for (int32_t i = 0; i < n_spheres; i++) {
-        const pt_sphere &s = spheres[i];
+    for (int32_t i = 0; i < n_prims; i++) {
+        if (prims[i].kind != PT_PRIM_SPHERE) continue;
+        const float *v = prims[i].v;
         const float lim = 4294967296.0f;
-        bounded = bounded && std::fabs(s.cx) <= lim && std::fabs(s.cy) <= lim && std::fabs(s.cz) <= lim && std::fabs(s.radius) <= lim;
+        bounded = bounded && std::fabs(v[0]) <= lim && std::fabs(v[1]) <= lim && std::fabs(v[2]) <= lim && std::fabs(v[3]) <= lim;
     }
     c->scene.bounded = bounded ? 1 : 0;
     c->have_scene = true;
+    return PT_OK;
+}
+
+int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, const pt_material *materials,
+                    int32_t n_materials, const pt_texture *textures, int32_t n_textures, const pt_bvh_node *nodes,
+                    int32_t n_nodes)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!spheres || n_spheres < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one sphere (bvh.rs:19)");
+    if (n_spheres > (1 << (30 - PT_CODE_SHIFT)))
+        return fail(c, PT_ERR_LIMIT, "too many spheres (%d): the node encoding holds at most %d", n_spheres, 1 << (30 - PT_CODE_SHIFT));
+    // BVH: caller's flattened tree, or build it here (bvh.rs:13-91)
+    std::vector<pt_bvh_node> built;
+    std::vector<pt_primitive> prims;
+    try {
+        prims.resize((size_t)n_spheres);
+        if (!nodes || n_nodes == 0) built.resize(2 * (size_t)n_spheres - 1);
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
+    }
+    if (!nodes || n_nodes == 0) {
+        const int32_t got = pt_bvh_build(spheres, n_spheres, built.data(), (int32_t)built.size());
+        if (got == PT_ERR_INVALID)
+            return fail(c, PT_ERR_INVALID, "BVH build: degenerate bounds (zero volume or non-finite) -- the reference panics here (bvh.rs:19)");
+        if (got != (int32_t)built.size()) return fail(c, PT_ERR_INVALID, "BVH build failed (%d)", got);
+        nodes = built.data();
+        n_nodes = got;
+    }
+    for (int32_t i = 0; i < n_spheres; i++)
+        prims[i] = pt_primitive{PT_PRIM_SPHERE, spheres[i].material, -1, 0, 0, {spheres[i].cx, spheres[i].cy, spheres[i].cz, spheres[i].radius, 0.0f}};
+    return upload_common(c, prims.data(), n_spheres, materials, n_materials, textures, n_textures, nullptr, 0, nodes, n_nodes, false);
+}
+
+int pt_upload_scene_ext(pt_context *c, const pt_primitive *prims, int32_t n_prims, const pt_material *materials,
+                        int32_t n_materials, const pt_texture *textures, int32_t n_textures, const pt_transform *transforms,
+                        int32_t n_transforms, const pt_bvh_node *nodes, int32_t n_nodes)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!prims || n_prims < 1) return fail(c, PT_ERR_INVALID, "scene needs at least one primitive (bvh.rs:19)");
+    if (n_transforms < 0 || (n_transforms > 0 && !transforms)) return fail(c, PT_ERR_INVALID, "bad transform array");
+    if (n_prims > (1 << (30 - PT_CODE_SHIFT)))
+        return fail(c, PT_ERR_LIMIT, "too many primitives (%d): the node encoding holds at most %d", n_prims, 1 << (30 - PT_CODE_SHIFT));
+    std::vector<pt_bvh_node> built;
+    if (!nodes || n_nodes == 0) {
+        try {
+            built.resize(2 * (size_t)n_prims - 1);
+        } catch (...) {
+            return fail(c, PT_ERR_INVALID, "out of host memory");
+        }
+        const int32_t got = pt_bvh_build_ext(prims, n_prims, transforms, n_transforms, built.data(), (int32_t)built.size());
+        if (got != (int32_t)built.size())
+            return fail(c, PT_ERR_INVALID, "BVH build over the primitives failed (%d): bad primitive fields or degenerate bounds", got);
+        nodes = built.data();
+        n_nodes = got;
+    }
+    return upload_common(c, prims, n_prims, materials, n_materials, textures, n_textures, transforms, n_transforms, nodes, n_nodes, true);
+}
+
+int pt_set_integrator(pt_context *c, const pt_integrator *integ)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!integ) { c->integrator = pt_integrator{5, 0, {0.0f, 0.0f, 0.0f}, -1}; return PT_OK; }
+    if (integ->max_bounces < 1 || integ->max_bounces > 1024) return fail(c, PT_ERR_INVALID, "max_bounces must be in [1, 1024] (got %d)", integ->max_bounces);
+    if (integ->background_kind != 0 && integ->background_kind != 1)
+        return fail(c, PT_ERR_INVALID, "background_kind must be 0 (sky gradient) or 1 (constant), got %d", integ->background_kind);
+    c->integrator = *integ;
     return PT_OK;
 }
 
@@ -510,6 +606,12 @@ static int render_device_with(pt_context *c, int32_t samples, uint64_t seed, int
     rp.inv_s1 = 1.0f / (float)(samples - 1);
     rp.inv_w = 1.0f / (float)c->camera.width;
     rp.inv_h = 1.0f / (float)c->camera.height;
+    rp.max_bounces = c->integrator.max_bounces;
+    rp.background_kind = c->integrator.background_kind;
+    rp.rr_start = c->integrator.rr_start;
+    rp.bg_r = c->integrator.background[0];
+    rp.bg_g = c->integrator.background[1];
+    rp.bg_b = c->integrator.background[2];
     rp.stats = nullptr;
 #ifdef PT_STATS
     static unsigned long long *d_stats = nullptr;

@@ -19,10 +19,13 @@ struct pt_context {
     // device scene
     float4 *d_nodes = nullptr;
     float4 *d_prims = nullptr;
+    float4 *d_xforms = nullptr;      // extension scenes: two float4 per pt_transform
     ptd::Texture *d_textures = nullptr;
     std::vector<uint8_t *> d_texels;
     ptd::Scene scene{};
     bool have_scene = false;
+
+    pt_integrator integrator{5, 0, {0.0f, 0.0f, 0.0f}, -1};   // pt_set_integrator; read by extension scenes only
 
     ptd::Camera camera{};
     bool have_camera = false;

@@ -195,6 +195,9 @@ struct Scene {
     int32_t root_code;       // node code of the root
     int32_t lds_nodes;       // n0[0 .. lds_nodes) is staged in LDS by the path kernel
     int32_t bounded;         // every sphere has |c_i| <= 2^32 and |r| <= 2^32 (see regular_ray)
+    // extension scenes only (pt_upload_scene_ext)
+    const float4 *xforms;    // per transform: (offset.xyz, sin theta), (cos theta, -, -, -)
+    int32_t ext;             // 1: rendered by the extension's kernel instantiation
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;
@@ -360,6 +363,44 @@ PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, con
     }
 }
 
+// ---- extension: rects and Translate(RotateY(..)) instances (NOT in the reference) ----------
+// Leaf of a rect:  n0 = (a0, a1, b0, b1)   n1 = (k, bits(flags), bits(prim), bits(next code))
+// flags: bit 0 = rect, bits 1-2 = axis, bit 3 = flip, bits 4.. = transform index + 1; a sphere's Leaf has flags 0.
+struct Xform { f3 off; float s, c; };
+PTD Xform load_xform(const Scene &sc, int idx)
+{
+    const float4 a = sc.xforms[2 * idx], b = sc.xforms[2 * idx + 1];
+    Xform x; x.off = mk(a.x, a.y, a.z); x.s = a.w; x.c = b.x;
+    return x;
+}
+PTD f3 rot_to_object(const Xform &x, f3 p) { return mk(x.c * p.x - x.s * p.z, p.y, x.s * p.x + x.c * p.z); }
+PTD f3 rot_to_world(const Xform &x, f3 p) { return mk(x.c * p.x + x.s * p.z, p.y, x.c * p.z - x.s * p.x); }
+PTD float pick(f3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+// the ray in the rect's object space (un-normalised: t is the same in both spaces)
+PTD void rect_object_ray(const Scene &sc, int flags, f3 &o, f3 &d)
+{
+    const int xf = (flags >> 4) - 1;
+    if (xf >= 0) {
+        const Xform x = load_xform(sc, xf);
+        o = rot_to_object(x, o - x.off);
+        d = rot_to_object(x, d);
+    }
+}
+// Traceable::trace of a rect: t = (k - o[axis]) / d[axis], accepted iff t < max_t && t > min_t (the
+// comparison of sphere.rs:57) and the point lies in [a0, a1] x [b0, b1]; a NaN fails every test
+PTD void rect_step(const Scene &sc, const float4 n0, const float4 n1, f3 o, f3 d, Hit &h)
+{
+    const int flags = __float_as_int(n1.y);
+    const int axis = (flags >> 1) & 3;
+    rect_object_ray(sc, flags, o, d);
+    const int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+    const float t = (n1.x - pick(o, axis)) / pick(d, axis);
+    if (!(t < h.t && t > T_MIN)) return;
+    const float a = pick(o, ia) + pick(d, ia) * t, b = pick(o, ib) + pick(d, ib) * t;
+    if (!(a >= n0.x && a <= n0.y && b >= n0.z && b <= n0.w)) return;
+    h.t = t; h.prim = __float_as_int(n1.z);
+}
+
 PTD bool finite3(f3 v)
 {
     return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z);
@@ -384,6 +425,7 @@ PTD bool regular_ray(const f3 inv, const f3 o, const float a, const bool bounded
 
 // whole-ray walk (used by the primary-hit kernel; the path kernel runs the same
 // steps from its state machine)
+template <bool EXT = false>
 PTD Hit scene_trace(const Scene &sc, const Ray &ray)
 {
     const f3 inv = mk(p_rcp(ray.d.x), p_rcp(ray.d.y), p_rcp(ray.d.z));           // scene/mod.rs:31: (1,1,1) / dir
@@ -395,38 +437,38 @@ PTD Hit scene_trace(const Scene &sc, const Ray &ray)
     while (code_index(code) < sc.n_nodes) {   // code_index(end code) == n_nodes
         const int i = code_index(code);
         const float4 n0 = sc.n0[i], n1 = sc.n1[i];
-        if (code < 0) { leaf_step(n0, n1, ray.o, ray.d, a, ra, regular, h); code = __float_as_int(n1.w); }
+        if (code < 0) {
+            if (EXT && (__float_as_int(n1.y) & 1)) rect_step(sc, n0, n1, ray.o, ray.d, h);
+            else leaf_step(n0, n1, ray.o, ray.d, a, ra, regular, h);
+            code = __float_as_int(n1.w);
+        }
         else code = regular ? split_step<true>(n0, n1, ray.o, inv, h.t) : split_step<false>(n0, n1, ray.o, inv, h.t);
     }
     return h;
 }
 
 // ---- Material::scatter (material/*.rs) -----------------------------------------
-// returns false when the path is absorbed (metal.rs:29-31)
-PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
+// The three Material::scatter bodies for a hit at p with normal n; returns false when the path is
+// absorbed (metal.rs:29-31).  They share their expensive pieces, so those are written once
+// and run once per step for the lanes of every material that needs them (each lane still
+// executes exactly its material's operations, in its material's order):
+//   reflect(d, n)            metal.rs:23, dielectric.rs:32
+//   random_in_unit_sphere    lambertian.rs:33, metal.rs:26 (drawn only if the ray is not absorbed)
+//   Ray::new's normalisation ray.rs:19-24
+// kind 3 (EXT only: a diffuse light) scatters nothing and draws nothing.
+template <bool EXT>
+PTD bool scatter_at(const Scene &sc, const Ray &ray, const f3 p, const f3 n, const int kind, const int tex, const float4 ma,
+                    uint64_t &rng, f3 &att, Ray &out)
 {
-    const float4 sp = sc.prims[2 * h.prim];
-    const float4 ma = sc.prims[2 * h.prim + 1];
-    const int2 mb = make_int2(__float_as_int(sp.w) & 3, (__float_as_int(sp.w) >> 2) - 1);   // (kind, texture or -1)
-    // Sphere::record (sphere.rs:37-42)
-    const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
-    const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));
-    // The three Material::scatter bodies share their expensive pieces, so those are written once
-    // and run once per step for the lanes of every material that needs them (each lane still
-    // executes exactly its material's operations, in its material's order):
-    //   reflect(d, n)            metal.rs:23, dielectric.rs:32
-    //   random_in_unit_sphere    lambertian.rs:33, metal.rs:26 (drawn only if the ray is not absorbed)
-    //   Ray::new's normalisation ray.rs:19-24
-    const int kind = mb.x;
     const f3 reflected = reflect(ray.d, n);                                      // unused by Lambertian lanes
-    bool alive = true;
+    bool alive = !EXT || kind != 3;
     if (kind == 1) alive = dot(reflected, n) > 0.0f;                             // metal.rs:25, else None (:29-31)
     f3 unit = fill(0.0f);
     if (kind == 0 || (kind == 1 && alive)) unit = random_in_unit_sphere(rng);
     f3 nd;
     if (kind == 0) {                                                             // lambertian.rs:32-45
         f3 target = (p + n) + unit;
-        att = (mb.y >= 0) ? sphere_uv_color(sc, mb.y, n) : mk(ma.x, ma.y, ma.z);
+        att = (tex >= 0) ? sphere_uv_color(sc, tex, n) : mk(ma.x, ma.y, ma.z);
         nd = target - p;
     } else if (kind == 1) {                                                      // metal.rs:22-32
         f3 fuzz = unit * ma.w;
@@ -442,7 +484,7 @@ PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f
         f3 refracted;
         att = fill(1.0f);
         nd = reflected;
-        if (refract(dir, outward, ni_over_nt, refracted)) {
+        if ((!EXT || kind == 2) && refract(dir, outward, ni_over_nt, refracted)) {
             float prob = schlick(cosine, ma.x);
             float r = rng_f32(rng);
             nd = (r < prob) ? reflected : refracted;
@@ -450,6 +492,46 @@ PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f
     }
     out.o = p; out.d = normalized(nd);                                           // ray.rs:19-24 (discarded when absorbed)
     return alive;
+}
+// Sphere::record (sphere.rs:37-42) + scatter for a hit sphere
+PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
+{
+    const float4 sp = sc.prims[2 * h.prim];
+    const float4 ma = sc.prims[2 * h.prim + 1];
+    const int2 mb = make_int2(__float_as_int(sp.w) & 3, (__float_as_int(sp.w) >> 2) - 1);   // (kind, texture or -1)
+    const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
+    const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));
+    return scatter_at<false>(sc, ray, p, n, mb.x, mb.y, ma, rng, att, out);
+}
+// Extension: the record of a sphere or a rect, the light's emitted term, then scatter.
+//   prims[2 i] of a rect = (bits(flags), -, -, bits(kind | 1 << 30)); flags as in its Leaf (rect_step)
+PTD bool scatter_ext(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out, f3 &emitted, bool &light)
+{
+    const float4 sp = sc.prims[2 * h.prim];
+    const float4 ma = sc.prims[2 * h.prim + 1];
+    const int tag = __float_as_int(sp.w);
+    const int kind = tag & 3;
+    f3 p, n;
+    if (tag & (1 << 30)) {
+        const int flags = __float_as_int(sp.x);
+        const int axis = (flags >> 1) & 3, xf = (flags >> 4) - 1;
+        f3 o = ray.o, d = ray.d;
+        rect_object_ray(sc, flags, o, d);
+        p = o + d * h.t;
+        const float one = (flags & 8) ? -1.0f : 1.0f;
+        n = mk(axis == 0 ? one : 0.0f, axis == 1 ? one : 0.0f, axis == 2 ? one : 0.0f);
+        if (xf >= 0) {
+            const Xform x = load_xform(sc, xf);
+            p = rot_to_world(x, p) + x.off;
+            n = rot_to_world(x, n);
+        }
+    } else {
+        p = ray.o + ray.d * h.t;
+        n = normalized(p - mk(sp.x, sp.y, sp.z));
+    }
+    light = kind == 3;
+    emitted = mk(ma.x, ma.y, ma.z);                                              // read only when `light`
+    return scatter_at<true>(sc, ray, p, n, kind, ((tag & 0x3fffffff) >> 2) - 1, ma, rng, att, out);
 }
 PTD f3 sky(const Ray &ray, f3 att)                                               // raytracer.rs:67-70
 {

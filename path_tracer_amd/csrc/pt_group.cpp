@@ -162,6 +162,41 @@ int pt_group_upload_scene(pt_group *g, const pt_sphere *spheres, int32_t n_spher
     return PT_OK;
 }
 
+int pt_group_upload_scene_ext(pt_group *g, const pt_primitive *prims, int32_t n_prims, const pt_material *materials,
+                              int32_t n_materials, const pt_texture *textures, int32_t n_textures,
+                              const pt_transform *transforms, int32_t n_transforms, const pt_bvh_node *nodes, int32_t n_nodes)
+{
+    if (!g) return PT_ERR_INVALID;
+    std::vector<pt_bvh_node> built;
+    if ((!nodes || n_nodes == 0) && prims && n_prims > 0) {
+        try {
+            built.resize(2 * (size_t)n_prims - 1);
+        } catch (...) {
+            return gfail(g, PT_ERR_INVALID, "out of host memory");
+        }
+        const int32_t got = pt_bvh_build_ext(prims, n_prims, transforms, n_transforms, built.data(), (int32_t)built.size());
+        if (got != (int32_t)built.size()) return gfail(g, got < 0 ? got : PT_ERR_INVALID, "BVH build over the primitives failed (%d)", got);
+        nodes = built.data();
+        n_nodes = got;
+    }
+    for (size_t r = 0; r < g->ctx.size(); r++) {
+        const int rc = pt_upload_scene_ext(g->ctx[r], prims, n_prims, materials, n_materials, textures, n_textures, transforms,
+                                           n_transforms, nodes, n_nodes);
+        if (rc != PT_OK) return rank_fail(g, (int)r, rc);
+    }
+    return PT_OK;
+}
+
+int pt_group_set_integrator(pt_group *g, const pt_integrator *integrator)
+{
+    if (!g) return PT_ERR_INVALID;
+    for (size_t r = 0; r < g->ctx.size(); r++) {
+        const int rc = pt_set_integrator(g->ctx[r], integrator);
+        if (rc != PT_OK) return rank_fail(g, (int)r, rc);
+    }
+    return PT_OK;
+}
+
 int pt_group_set_camera(pt_group *g, const pt_camera *camera)
 {
     if (!g) return PT_ERR_INVALID;

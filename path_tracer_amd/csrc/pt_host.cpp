@@ -107,6 +107,44 @@ struct Builder {
     }
 };
 
+// ---- extension (include/pt_amd.h): boxes of rects and instances ----
+inline void rect_axes(int axis, int &ia, int &ib) { ia = axis == 0 ? 1 : 0; ib = axis == 2 ? 1 : 2; }
+// object space -> world: rotation about y by +theta
+inline void rot_to_world(const pt_transform &x, const float p[3], float w[3])
+{
+    w[0] = x.cos_theta * p[0] + x.sin_theta * p[2];
+    w[1] = p[1];
+    w[2] = x.cos_theta * p[2] - x.sin_theta * p[0];
+}
+// bounding_box() of a rect: padded by 0.0001 on its thin axis (a flat box has volume 0, which
+// turns every split cost of bvh.rs:65 into NaN); an instance: the box of the 8 rotated corners, + offset
+inline Box rect_box(const pt_primitive &p, const pt_transform *xforms)
+{
+    float lo[3], hi[3];
+    int ia, ib;
+    rect_axes(p.axis, ia, ib);
+    lo[p.axis] = p.v[4] - 0.0001f; hi[p.axis] = p.v[4] + 0.0001f;
+    lo[ia] = p.v[0]; hi[ia] = p.v[1];
+    lo[ib] = p.v[2]; hi[ib] = p.v[3];
+    Box b;
+    if (p.transform < 0) {
+        for (int k = 0; k < 3; k++) { b.mn[k] = lo[k]; b.mx[k] = hi[k]; }
+        return b;
+    }
+    const pt_transform &x = xforms[p.transform];
+    for (int c = 0; c < 8; c++) {
+        const float corner[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+        float w[3];
+        rot_to_world(x, corner, w);
+        for (int k = 0; k < 3; k++) {
+            if (c == 0) { b.mn[k] = w[k]; b.mx[k] = w[k]; }
+            else { b.mn[k] = lane_min(w[k], b.mn[k]); b.mx[k] = lane_max(w[k], b.mx[k]); }
+        }
+    }
+    for (int k = 0; k < 3; k++) { b.mn[k] = b.mn[k] + x.offset[k]; b.mx[k] = b.mx[k] + x.offset[k]; }
+    return b;
+}
+
 // rng.rs restated for the seeded generators
 struct HostRng {
     uint64_t s;
@@ -140,6 +178,78 @@ int32_t pt_bvh_build(const pt_sphere *spheres, int32_t n_spheres, pt_bvh_node *o
     } catch (...) {
         return PT_ERR_LIMIT;   // out of host memory
     }
+}
+
+int32_t pt_bvh_build_ext(const pt_primitive *prims, int32_t n_prims, const pt_transform *transforms, int32_t n_transforms,
+                         pt_bvh_node *out, int32_t capacity)
+{
+    if (!prims || !out || n_prims < 1 || n_transforms < 0 || (n_transforms > 0 && !transforms)) return PT_ERR_INVALID;
+    const int64_t need = 2ll * n_prims - 1;
+    if (capacity < need) return PT_ERR_LIMIT;
+    for (int32_t i = 0; i < n_prims; i++) {
+        const pt_primitive &p = prims[i];
+        if (p.kind == PT_PRIM_RECT) {
+            if (p.axis < 0 || p.axis > 2 || p.transform < -1 || p.transform >= n_transforms) return PT_ERR_INVALID;
+        } else if (p.kind != PT_PRIM_SPHERE || p.transform != -1) {
+            return PT_ERR_INVALID;
+        }
+    }
+    try {
+        Builder b;
+        b.items.resize((size_t)n_prims);
+        b.suffix.resize((size_t)n_prims);
+        b.out = out;
+        for (int32_t i = 0; i < n_prims; i++) {
+            const pt_primitive &p = prims[i];
+            b.items[i].prim = i;
+            if (p.kind == PT_PRIM_RECT) b.items[i].box = rect_box(p, transforms);
+            else b.items[i].box = sphere_box(pt_sphere{p.v[0], p.v[1], p.v[2], p.v[3], p.material});
+        }
+        b.construct(0, n_prims);
+        if (b.degenerate) return PT_ERR_INVALID;
+        return b.next;
+    } catch (...) {
+        return PT_ERR_LIMIT;
+    }
+}
+
+// "Ray Tracing: The Next Week", cornell_box(): five walls of the 555-unit room, the light under the
+// ceiling, two boxes (six rects each) as Translate(RotateY(box)) instances.
+int32_t pt_gen_cornell_box(pt_primitive *prims, int32_t prim_capacity, pt_material *materials, int32_t material_capacity,
+                           pt_transform *transforms, int32_t transform_capacity)
+{
+    if (!prims || !materials || !transforms) return PT_ERR_INVALID;
+    if (prim_capacity < 18 || material_capacity < 4 || transform_capacity < 2) return PT_ERR_LIMIT;
+    enum { RED = 0, WHITE = 1, GREEN = 2, LIGHT = 3 };
+    materials[RED] = pt_material{PT_LAMBERTIAN, {0.65f, 0.05f, 0.05f}, 0.0f, -1};
+    materials[WHITE] = pt_material{PT_LAMBERTIAN, {0.73f, 0.73f, 0.73f}, 0.0f, -1};
+    materials[GREEN] = pt_material{PT_LAMBERTIAN, {0.12f, 0.45f, 0.15f}, 0.0f, -1};
+    materials[LIGHT] = pt_material{PT_DIFFUSE_LIGHT, {15.0f, 15.0f, 15.0f}, 0.0f, -1};
+    int32_t n = 0;
+    auto rect = [&](int axis, float a0, float a1, float b0, float b1, float k, int material, int flip, int transform) {
+        prims[n++] = pt_primitive{PT_PRIM_RECT, material, transform, axis, flip, {a0, a1, b0, b1, k}};
+    };
+    rect(0, 0.0f, 555.0f, 0.0f, 555.0f, 555.0f, GREEN, 1, -1);          // flip_normals(yz_rect(0,555,0,555,555, green))
+    rect(0, 0.0f, 555.0f, 0.0f, 555.0f, 0.0f, RED, 0, -1);              // yz_rect(0,555,0,555,0, red)
+    rect(1, 213.0f, 343.0f, 227.0f, 332.0f, 554.0f, LIGHT, 0, -1);      // xz_rect(213,343,227,332,554, light)
+    rect(1, 0.0f, 555.0f, 0.0f, 555.0f, 555.0f, WHITE, 1, -1);          // flip_normals(xz_rect(.., 555, white))
+    rect(1, 0.0f, 555.0f, 0.0f, 555.0f, 0.0f, WHITE, 0, -1);            // xz_rect(.., 0, white)
+    rect(2, 0.0f, 555.0f, 0.0f, 555.0f, 555.0f, WHITE, 1, -1);          // flip_normals(xy_rect(.., 555, white))
+    // box(p0, p1): xy at z1, flipped xy at z0, xz at y1, flipped xz at y0, yz at x1, flipped yz at x0
+    auto box = [&](float x1, float y1, float z1, int transform) {
+        rect(2, 0.0f, x1, 0.0f, y1, z1, WHITE, 0, transform);
+        rect(2, 0.0f, x1, 0.0f, y1, 0.0f, WHITE, 1, transform);
+        rect(1, 0.0f, x1, 0.0f, z1, y1, WHITE, 0, transform);
+        rect(1, 0.0f, x1, 0.0f, z1, 0.0f, WHITE, 1, transform);
+        rect(0, 0.0f, y1, 0.0f, z1, x1, WHITE, 0, transform);
+        rect(0, 0.0f, y1, 0.0f, z1, 0.0f, WHITE, 1, transform);
+    };
+    const float deg = 3.14159265358979323846f / 180.0f;
+    transforms[0] = pt_transform{{130.0f, 0.0f, 65.0f}, std::sin(-18.0f * deg), std::cos(-18.0f * deg)};
+    transforms[1] = pt_transform{{265.0f, 0.0f, 295.0f}, std::sin(15.0f * deg), std::cos(15.0f * deg)};
+    box(165.0f, 165.0f, 165.0f, 0);
+    box(165.0f, 330.0f, 165.0f, 1);
+    return n;
 }
 
 int pt_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_degrees, int32_t width,

@@ -160,7 +160,9 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
     return code;
 }
 
-template <bool ALL_IN_LDS>
+// EXT: the instantiation for scenes uploaded with pt_upload_scene_ext (rects, instances, lights, integrator
+// options).  The reference's scenes always run EXT = false, whose code is unchanged.
+template <bool ALL_IN_LDS, bool EXT = false>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
                                                                     float *radiance)
 {
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     Hit h; h.t = T_MAX; h.prim = -1;
     int32_t code = C_DONE;
     f3 att = fill(1.0f);
+    f3 rad = fill(0.0f);          // EXT: radiance the path has collected from lights so far
     int bounce = 0;
     uint64_t rng = 0;
     bool regular = true;
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             else {
                 ray = sample_ray_grid(cam, S, rp.inv_s1, rp.inv_w, rp.inv_h, px, py, (int)(sxy >> 16), (int)(sxy & 0xffffu));   // raytracer.rs:77-85
                 att = fill(1.0f);                                                // raytracer.rs:50
+                if (EXT) rad = fill(0.0f);
                 bounce = 0;
                 rng = path_rng(rp.seed, pixel, (uint32_t)s);
                 new_walk = true;
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                         PT_STAT(1, lanes(true));
                         float4 n0, n1;
                         fetch(code, n0, n1);
-                        leaf_step(n0, n1, ray.o, ray.d, a, ra, PT_FAST_DIV && all_regular, h);
+                        if (EXT && (__float_as_int(n1.y) & 1)) rect_step(sc, n0, n1, ray.o, ray.d, h);
+                        else leaf_step(n0, n1, ray.o, ray.d, a, ra, PT_FAST_DIV && all_regular, h);
                         code = __float_as_int(n1.w);
                         const bool at = code < 0;
                         const bool few = lanes(at) < keepL;
@@ -377,11 +382,29 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             PT_STAT(2, lanes(walked && h.prim >= 0));
             if (walked && h.prim >= 0) {
                 f3 am; Ray nr;
-                if (scatter(sc, ray, h, rng, am, nr)) {
+                bool scattered;
+                if (EXT) {
+                    f3 emitted; bool light;
+                    scattered = scatter_ext(sc, ray, h, rng, am, nr, emitted, light);
+                    if (light) rad = rad + emitted * att;                        // Material::emitted, before scatter's verdict
+                } else {
+                    scattered = scatter(sc, ray, h, rng, am, nr);
+                }
+                if (scattered) {
                     att = att * am;                                              // raytracer.rs:57
                     ray = nr;
                     bounce++;
-                    if (bounce >= 5) ended = true;                               // MAX_TRACES, raytracer.rs:48
+                    bool killed = false;
+                    if (EXT && rp.rr_start >= 0 && bounce >= rp.rr_start) {      // Russian roulette on the largest component
+                        const float q = __builtin_fmaxf(att.x, __builtin_fmaxf(att.y, att.z));
+                        if (q < 1.0f) {
+                            const float r = rng_f32(rng);
+                            if (!(r < q)) killed = true;
+                            else att = att / q;
+                        }
+                    }
+                    if (killed) { ended = true; to_sky = false; }
+                    else if (bounce >= (EXT ? rp.max_bounces : 5)) ended = true; // MAX_TRACES, raytracer.rs:48
                     else new_walk = true;
                 } else {
                     ended = true; to_sky = false;                                // raytracer.rs:60: return 0
@@ -390,8 +413,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
             PT_TIME(2);
             PT_STAT(3, lanes(ended));
             if (ended) {
-                f3 color = fill(0.0f);
-                if (to_sky) color = sky(ray, att);                               // raytracer.rs:67-70
+                f3 color = EXT ? rad : fill(0.0f);
+                if (to_sky) {
+                    if (!EXT) color = sky(ray, att);                             // raytracer.rs:67-70
+                    else if (rp.background_kind == 0) color = rad + sky(ray, att);
+                    else color = rad + mk(rp.bg_r, rp.bg_g, rp.bg_b) * att;
+                }
                 sum = sum + color;                                               // raytracer.rs:88
                 s++;
                 sxy++;
@@ -434,6 +461,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
 }
 
 // K1: primitive id (and t) hit by the primary ray of one sample index.
+template <bool EXT>
 __global__ __launch_bounds__(64) void primary_hit_kernel(Scene sc, Camera cam, int S, int sample, int32_t *__restrict__ hit_id,
                                                          float *__restrict__ hit_t)
 {
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(64) void primary_hit_kernel(Scene sc, Camera cam, i
     const int py = (blockIdx.x / tiles_x) * 8 + (lane >> 3);
     if (px >= cam.width || py >= cam.height) return;
     const Ray ray = sample_ray(cam, S, px, py, sample);
-    const Hit h = scene_trace(sc, ray);
+    const Hit h = scene_trace<EXT>(sc, ray);
     const int pixel = py * cam.width + px;
     if (hit_id) hit_id[pixel] = h.prim;
     if (hit_t) hit_t[pixel] = h.t;
@@ -650,12 +678,15 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
     const size_t lds_bytes = ((size_t)sc.lds_nodes + 1) * sizeof(float4);   // + the ticket word
-    if (sc.lds_nodes >= sc.n_nodes)
-        hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
-                           rp, sp, d_radiance);
-    else
-        hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)groups), dim3(64 * WAVES_PER_GROUP), lds_bytes, stream, sc, cam,
-                           rp, sp, d_radiance);
+    const dim3 grid((unsigned)groups), block(64 * WAVES_PER_GROUP);
+    const bool in_lds = sc.lds_nodes >= sc.n_nodes;
+    if (!sc.ext) {
+        if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+        else hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+    } else {
+        if (in_lds) hipLaunchKernelGGL((path_kernel<true, true>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+        else hipLaunchKernelGGL((path_kernel<false, true>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+    }
     return hipGetLastError();
 }
 
@@ -663,7 +694,8 @@ hipError_t launch_primary_hits(const Scene &sc, const Camera &cam, int S, int sa
                                hipStream_t stream)
 {
     const int tiles = tiles_for(cam, 1);
-    hipLaunchKernelGGL(primary_hit_kernel, dim3(tiles), dim3(64), 0, stream, sc, cam, S, sample, d_hit_id, d_hit_t);
+    if (sc.ext) hipLaunchKernelGGL(primary_hit_kernel<true>, dim3(tiles), dim3(64), 0, stream, sc, cam, S, sample, d_hit_id, d_hit_t);
+    else hipLaunchKernelGGL(primary_hit_kernel<false>, dim3(tiles), dim3(64), 0, stream, sc, cam, S, sample, d_hit_id, d_hit_t);
     return hipGetLastError();
 }
 

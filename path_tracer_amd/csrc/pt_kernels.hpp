@@ -9,6 +9,9 @@ struct RenderParams {
     int32_t lanes;        // lanes per pixel: power of two in [1, 64]
     int32_t accumulate;   // continue the sum already in the radiance buffer
     float inv_s1, inv_w, inv_h;   // 1/(S-1), 1/W, 1/H: correctly rounded fp32 reciprocals (host), for div_by
+    // extension scenes only (pt_set_integrator; defaults = the reference's constants)
+    int32_t max_bounces, background_kind, rr_start;
+    float bg_r, bg_g, bg_b;
     unsigned long long *stats;   // PT_STATS builds only: {steps, active lanes} x {SPLIT, LEAF, SHADE:hit, SHADE:end}, then 6 cycle buckets
 };
 

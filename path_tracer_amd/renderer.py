@@ -56,9 +56,17 @@ class ParallelRenderer:
         p = raytracer.packed
         tex = p.texture_structs()
         nodes = raytracer.nodes
-        _abi.check(self._ctx, _abi.lib().pt_upload_scene(
-            self._ctx, p.spheres, p.n_spheres, p.materials, p.n_materials, tex, len(p.textures),
-            nodes, len(nodes) if nodes is not None else 0))
+        if hasattr(p, "prims"):          # extension scene (rects, lights, instances, integrator options)
+            _abi.check(self._ctx, _abi.lib().pt_upload_scene_ext(
+                self._ctx, p.prims, p.n_prims, p.materials, p.n_materials, tex, len(p.textures),
+                p.transforms if len(p.transforms) else None, len(p.transforms),
+                nodes, len(nodes) if nodes is not None else 0))
+            _abi.check(self._ctx, _abi.lib().pt_set_integrator(
+                self._ctx, C.byref(raytracer.integrator.pod) if raytracer.integrator is not None else None))
+        else:
+            _abi.check(self._ctx, _abi.lib().pt_upload_scene(
+                self._ctx, p.spheres, p.n_spheres, p.materials, p.n_materials, tex, len(p.textures),
+                nodes, len(nodes) if nodes is not None else 0))
         _abi.check(self._ctx, _abi.lib().pt_set_camera(self._ctx, C.byref(raytracer.camera.pod)))
         self._raytracer = raytracer
 
@@ -206,9 +214,17 @@ class RendererGroup:
         p = raytracer.packed
         tex = p.texture_structs()
         nodes = raytracer.nodes
-        self._check(_abi.lib().pt_group_upload_scene(
-            self._grp, p.spheres, p.n_spheres, p.materials, p.n_materials, tex, len(p.textures),
-            nodes, len(nodes) if nodes is not None else 0))
+        if hasattr(p, "prims"):
+            self._check(_abi.lib().pt_group_upload_scene_ext(
+                self._grp, p.prims, p.n_prims, p.materials, p.n_materials, tex, len(p.textures),
+                p.transforms if len(p.transforms) else None, len(p.transforms),
+                nodes, len(nodes) if nodes is not None else 0))
+            self._check(_abi.lib().pt_group_set_integrator(
+                self._grp, C.byref(raytracer.integrator.pod) if raytracer.integrator is not None else None))
+        else:
+            self._check(_abi.lib().pt_group_upload_scene(
+                self._grp, p.spheres, p.n_spheres, p.materials, p.n_materials, tex, len(p.textures),
+                nodes, len(nodes) if nodes is not None else 0))
         self._check(_abi.lib().pt_group_set_camera(self._grp, C.byref(raytracer.camera.pod)))
         self._raytracer = raytracer
 
@@ -246,9 +262,12 @@ class Raytracer:
     (Scene::construct_bvh, scene/mod.rs:50-60) -- here with pt_bvh_build on the host,
     flattened for the GPU."""
 
-    def __init__(self, camera, scene, samples, build_bvh=True):
+    def __init__(self, camera, scene, samples, build_bvh=True, integrator=None):
         if not isinstance(camera, Camera) or not isinstance(scene, Scene):
             raise TypeError("Raytracer.new(camera: Camera, scene: Scene, samples)")
+        if integrator is not None and not scene.is_ext():
+            raise ValueError("integrator options apply to extension scenes only (Rect / DiffuseLight / Scene.force_ext)")
+        self.integrator = integrator       # extension: scene.Integrator or None (= the reference's constants)
         if int(samples) < 2:
             # samples == 1 divides 0/0 in the sample grid (raytracer.rs:78); the library refuses it too
             raise ValueError("samples must be >= 2")
@@ -257,8 +276,8 @@ class Raytracer:
         self.nodes = self.packed.build_bvh() if build_bvh else None   # None: the library builds it at upload
 
     @classmethod
-    def new(cls, camera, scene, samples):
-        return cls(camera, scene, samples)
+    def new(cls, camera, scene, samples, integrator=None):
+        return cls(camera, scene, samples, integrator=integrator)
 
     def width(self):
         return self.camera.width

@@ -115,12 +115,81 @@ class Dielectric:
         return cls(ref_idx)
 
 
+class DiffuseLight:
+    """EXTENSION (not in the reference; include/pt_amd.h): a material whose
+    ``scatter`` returns None and whose ``emitted`` term is ``color`` (e.g. (15, 15, 15))."""
+
+    def __init__(self, color):
+        self.color = _f3(color)
+
+    @classmethod
+    def new(cls, color):
+        return cls(color)
+
+
+class Transform:
+    """EXTENSION: Translate(RotateY(object)) -- rotate about y by ``degrees``, then move by ``offset``.
+    sin / cos are computed here (host libm) and cross the ABI as values."""
+
+    def __init__(self, offset, degrees):
+        self.offset = _f3(offset)
+        rad = np.float32(degrees) * (np.float32(np.pi) / np.float32(180.0))
+        self.sin_theta, self.cos_theta = float(np.sin(rad, dtype=np.float32)), float(np.cos(rad, dtype=np.float32))
+
+    @classmethod
+    def new(cls, offset, degrees):
+        return cls(offset, degrees)
+
+    @classmethod
+    def from_sin_cos(cls, offset, sin_theta, cos_theta):
+        t = cls.__new__(cls)
+        t.offset, t.sin_theta, t.cos_theta = _f3(offset), float(np.float32(sin_theta)), float(np.float32(cos_theta))
+        return t
+
+
+class Rect:
+    """EXTENSION: an axis-aligned rectangle, the plane ``axis`` = k (0: yz-rect, 1: xz-rect, 2: xy-rect)
+    over [a0, a1] x [b0, b1] on the two other axes in increasing axis order; normal = the axis' unit
+    vector, negated by ``flip``; optional ``transform``."""
+
+    def __init__(self, axis, a0, a1, b0, b1, k, material, flip=False, transform=None):
+        if axis not in (0, 1, 2):
+            raise ValueError("axis must be 0, 1 or 2")
+        if not isinstance(material, (Lambertian, Metal, Dielectric, DiffuseLight)):
+            raise TypeError("material must be Lambertian, Metal, Dielectric or DiffuseLight")
+        if transform is not None and not isinstance(transform, Transform):
+            raise TypeError("transform must be a Transform")
+        self.axis, self.flip, self.material, self.transform = int(axis), bool(flip), material, transform
+        self.v = tuple(float(np.float32(x)) for x in (a0, a1, b0, b1, k))
+
+    @classmethod
+    def new(cls, *args, **kw):
+        return cls(*args, **kw)
+
+
+def box_rects(p0, p1, material, transform=None):
+    """EXTENSION: the six rects of an axis-aligned box from p0 to p1 (outward normals)."""
+    (x0, y0, z0), (x1, y1, z1) = _f3(p0), _f3(p1)
+    return [Rect(2, x0, x1, y0, y1, z1, material, False, transform), Rect(2, x0, x1, y0, y1, z0, material, True, transform),
+            Rect(1, x0, x1, z0, z1, y1, material, False, transform), Rect(1, x0, x1, z0, z1, y0, material, True, transform),
+            Rect(0, y0, y1, z0, z1, x1, material, False, transform), Rect(0, y0, y1, z0, z1, x0, material, True, transform)]
+
+
+class Integrator:
+    """EXTENSION: trace_ray's constants as parameters (pt_integrator).  Defaults = the reference:
+    5 bounces (raytracer.rs:48), the sky gradient (raytracer.rs:67-68), no Russian roulette."""
+
+    def __init__(self, max_bounces=5, background=None, rr_start=-1):
+        bg = _f3(background) if background is not None else (0.0, 0.0, 0.0)
+        self.pod = _abi.PtIntegrator(int(max_bounces), 0 if background is None else 1, (C.c_float * 3)(*bg), int(rr_start))
+
+
 class Sphere:
     """traceable/sphere.rs:20-34"""
 
     def __init__(self, center, radius, material):
-        if not isinstance(material, (Lambertian, Metal, Dielectric)):
-            raise TypeError("material must be Lambertian, Metal or Dielectric")
+        if not isinstance(material, (Lambertian, Metal, Dielectric, DiffuseLight)):
+            raise TypeError("material must be Lambertian, Metal or Dielectric (or the extension's DiffuseLight)")
         self.center, self.radius, self.material = _f3(center), float(np.float32(radius)), material
 
     @classmethod
@@ -156,32 +225,72 @@ class PackedScene:
         return nodes
 
 
+class PackedSceneExt:
+    """EXTENSION: the plain arrays of pt_upload_scene_ext (pt_primitive[], pt_material[], pt_texture[], pt_transform[])."""
+
+    def __init__(self, prims, materials, textures, transforms):
+        self.prims, self.materials, self.textures, self.transforms = prims, materials, textures, transforms
+        self.n_prims, self.n_materials = len(prims), len(materials)
+        self.n_spheres = self.n_prims          # primitive count, under the name the benchmark reports
+
+    texture_structs = PackedScene.texture_structs
+
+    def build_bvh(self):
+        cap = 2 * self.n_prims - 1
+        nodes = (_abi.PtBvhNode * cap)()
+        got = _abi.lib().pt_bvh_build_ext(self.prims, self.n_prims, self.transforms if len(self.transforms) else None,
+                                          len(self.transforms), nodes, cap)
+        if got != cap:
+            raise _abi.PtError(got, "pt_bvh_build_ext failed")
+        return nodes
+
+
 class Scene:
     """scene/mod.rs: an ordered object list; primitive id = insertion order (mod.rs:46-48)."""
 
     def __init__(self):
         self.objects = []
+        self.force_ext = False      # render a sphere-only scene through the extension's entry points (tests)
 
     @classmethod
     def new(cls):
         return cls()
 
     def add(self, obj):
-        if not isinstance(obj, Sphere):
-            raise TypeError("only Sphere implements Traceable (traceable/mod.rs)")
+        if not isinstance(obj, (Sphere, Rect)):
+            raise TypeError("only Sphere implements Traceable (traceable/mod.rs); the extension adds Rect")
         self.objects.append(obj)
+
+    def is_ext(self):
+        return self.force_ext or any(isinstance(o, Rect) or isinstance(o.material, DiffuseLight) for o in self.objects)
 
     def pack(self):
         if not self.objects:
             raise ValueError("Cannot build BVH without any objects.")   # bvh.rs:19
         mats, mat_index, texs, tex_index = [], {}, [], {}
-        spheres = (_abi.PtSphere * len(self.objects))()
+        ext = self.is_ext()
+        spheres = None if ext else (_abi.PtSphere * len(self.objects))()
+        prims = (_abi.PtPrimitive * len(self.objects))() if ext else None
+        xforms, xform_index = [], {}
         for i, o in enumerate(self.objects):
             m = o.material
             if id(m) not in mat_index:                       # shared Arc<dyn Material>: one entry
                 mat_index[id(m)] = len(mats)
                 mats.append(m)
-            spheres[i] = _abi.PtSphere(o.center[0], o.center[1], o.center[2], o.radius, mat_index[id(m)])
+            if not ext:
+                spheres[i] = _abi.PtSphere(o.center[0], o.center[1], o.center[2], o.radius, mat_index[id(m)])
+            elif isinstance(o, Sphere):
+                prims[i] = _abi.PtPrimitive(_abi.PT_PRIM_SPHERE, mat_index[id(m)], -1, 0, 0,
+                                            (C.c_float * 5)(o.center[0], o.center[1], o.center[2], o.radius, 0.0))
+            else:
+                t = -1
+                if o.transform is not None:
+                    if id(o.transform) not in xform_index:
+                        xform_index[id(o.transform)] = len(xforms)
+                        xforms.append(o.transform)
+                    t = xform_index[id(o.transform)]
+                prims[i] = _abi.PtPrimitive(_abi.PT_PRIM_RECT, mat_index[id(m)], t, o.axis, 1 if o.flip else 0,
+                                            (C.c_float * 5)(*o.v))
         materials = (_abi.PtMaterial * len(mats))()
         for i, m in enumerate(mats):
             if isinstance(m, Lambertian):
@@ -195,9 +304,16 @@ class Scene:
                 materials[i] = _abi.PtMaterial(_abi.PT_LAMBERTIAN, (C.c_float * 3)(*alb), 0.0, tex)
             elif isinstance(m, Metal):
                 materials[i] = _abi.PtMaterial(_abi.PT_METAL, (C.c_float * 3)(*m.albedo), m.fuziness, -1)
+            elif isinstance(m, DiffuseLight):
+                materials[i] = _abi.PtMaterial(_abi.PT_DIFFUSE_LIGHT, (C.c_float * 3)(*m.color), 0.0, -1)
             else:
                 materials[i] = _abi.PtMaterial(_abi.PT_DIELECTRIC, (C.c_float * 3)(0.0, 0.0, 0.0), m.ref_idx, -1)
-        return PackedScene(spheres, materials, texs)
+        if not ext:
+            return PackedScene(spheres, materials, texs)
+        transforms = (_abi.PtTransform * len(xforms))()
+        for i, t in enumerate(xforms):
+            transforms[i] = _abi.PtTransform((C.c_float * 3)(*t.offset), t.sin_theta, t.cos_theta)
+        return PackedSceneExt(prims, materials, texs, transforms)
 
 
 class Camera:
@@ -265,3 +381,22 @@ def random_scene(scene, seed, bounds=REFERENCE_BOUNDS):
     if n != cap:
         raise _abi.PtError(n, "pt_gen_random_scene failed")
     _from_arrays(scene, spheres, materials, n)
+
+
+# The room of "Ray Tracing: The Next Week" (cornell_box()), camera of its main(): BASELINE config 4
+CORNELL_CAMERA = dict(eyes=(278.0, 278.0, -800.0), target=(278.0, 278.0, 0.0), up=(0.0, 1.0, 0.0), fov=40.0)
+
+
+def cornell_box(scene):
+    """EXTENSION: pt_gen_cornell_box -- five walls, the light, two rotated boxes (18 rects)."""
+    prims, materials, transforms = (_abi.PtPrimitive * 18)(), (_abi.PtMaterial * 4)(), (_abi.PtTransform * 2)()
+    n = _abi.lib().pt_gen_cornell_box(prims, 18, materials, 4, transforms, 2)
+    if n != 18:
+        raise _abi.PtError(n, "pt_gen_cornell_box failed")
+    mats = []
+    for m in materials:
+        mats.append(DiffuseLight.new(tuple(m.albedo)) if m.kind == _abi.PT_DIFFUSE_LIGHT else Lambertian.new_solid(tuple(m.albedo)))
+    xf = [Transform.from_sin_cos(tuple(t.offset), t.sin_theta, t.cos_theta) for t in transforms]
+    for p in prims:
+        scene.add(Rect(p.axis, p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], mats[p.material], bool(p.flip),
+                       xf[p.transform] if p.transform >= 0 else None))

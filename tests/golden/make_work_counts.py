@@ -19,13 +19,20 @@ import bench  # noqa: E402  (workload table + scene construction only)
 import oracle_lib  # noqa: E402
 import path_tracer_amd as pt  # noqa: E402
 
-out = {}
+# usage: make_work_counts.py [workload ...]   (no argument: all; named ones are merged into the existing file)
+PATH = os.path.join(ROOT, "path_tracer_amd", "data", "work_counts.json")
+only = sys.argv[1:]
+out = json.load(open(PATH)) if (only and os.path.exists(PATH)) else {}
 for name, (scene_kind, w, h, samples, desc) in bench.WORKLOADS.items():
+    if only and name not in only:
+        continue
     s = 2
     while (s + 1) ** 2 * w * h <= 20e6 and s + 1 <= samples:
         s += 1
     rt = bench.build_raytracer(pt, scene_kind, w, h, s)
     osc = oracle_lib.OracleScene(rt.packed)
+    if getattr(rt, "integrator", None) is not None:
+        osc.set_integrator(rt.integrator.pod)
     c = osc.render(rt.camera.pod, s, seed=bench.RENDER_SEED, counters=True)["counters"]
     flops = oracle_lib.algorithmic_flops(c)
     out[name] = {
@@ -36,5 +43,5 @@ for name, (scene_kind, w, h, samples, desc) in bench.WORKLOADS.items():
         "rng_draws_per_path": c["rng_draws"] / c["paths"], "counters": c, "flop_model": oracle_lib.FLOPS,
     }
     print(name, out[name]["measured_at"], "flops/path = %.1f" % out[name]["flops_per_path"], flush=True)
-with open(os.path.join(ROOT, "path_tracer_amd", "data", "work_counts.json"), "w") as f:
+with open(PATH, "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
