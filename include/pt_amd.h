@@ -184,6 +184,17 @@ int pt_render_progress(pt_context *ctx, int32_t samples, uint64_t seed, int32_t 
  * kernel (pt_last_error says which) -- the way to check a pt_render_device launch. */
 float pt_last_path_kernel_ms(pt_context *ctx);
 
+/* Arithmetic mode of the path kernel.  No counterpart in the reference.
+ *   PT_EXACT (default): every + - * / sqrt is one correctly rounded fp32 operation in the reference's
+ *            order, nothing fused (Rust never contracts a * b + c): radiance equals the oracle's bit for bit.
+ *   PT_FAST : opt-in.  Fused multiply-adds, hardware reciprocal / square-root estimates, the slab test
+ *            with one fma per plane.  Within BASELINE's tolerance of the EXACT result (>= 99.9 % of
+ *            pixels within 1/255 after tonemapping at equal spp and seed, converged RMSE < 1e-3), not
+ *            bit-equal to it.  Applies to pt_upload_scene scenes; the hit-id AOV, the resolve and the
+ *            extension's scenes (pt_upload_scene_ext) always run EXACT. */
+enum { PT_EXACT = 0, PT_FAST = 1 };
+int pt_set_mode(pt_context *ctx, int32_t mode);
+
 /* How a pixel's samples are spread over GPU lanes.  0 (default) = automatic:
  * one lane owns all samples of a pixel whenever the frame alone fills the GPU,
  * which reproduces the reference's sequential fp32 sum order (raytracer.rs:88)

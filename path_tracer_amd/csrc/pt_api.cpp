@@ -579,6 +579,14 @@ int pt_set_lanes_per_pixel(pt_context *c, int32_t lanes)
     return PT_OK;
 }
 
+int pt_set_mode(pt_context *c, int32_t mode)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (mode != PT_EXACT && mode != PT_FAST) return fail(c, PT_ERR_INVALID, "mode must be PT_EXACT (0) or PT_FAST (1), got %d", mode);
+    c->mode = mode;
+    return PT_OK;
+}
+
 int pt_get_lanes_per_pixel(const pt_context *c, int32_t samples, int32_t sample_begin, int32_t sample_end)
 {
     if (!c || !c->have_camera || samples < 2 || sample_end <= sample_begin) return PT_ERR_INVALID;
@@ -627,7 +635,8 @@ static int render_device_with(pt_context *c, int32_t samples, uint64_t seed, int
     PT_HIP(c, hipEventRecord(c->ev_start, st));
     c->last_sched = sched;
     c->last_stream = st;
-    PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
+    if (c->mode == PT_FAST && !c->scene.ext) PT_HIP(c, ptk_fast::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
+    else PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
     PT_HIP(c, hipEventRecord(c->ev_stop, st));
     c->timed = true;
 #ifdef PT_STATS

@@ -37,6 +37,7 @@ struct pt_context {
     int64_t frame_pixels = 0;
 
     int32_t lanes_override = 0;
+    int32_t mode = PT_EXACT;      // pt_set_mode
 
     int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
     size_t sched_bytes = 0;

@@ -15,7 +15,40 @@ namespace ptd {
 
 struct f3 { float x, y, z; };
 
+// ---- device scene -------------------------------------------------------------
+struct Texture { const uint8_t *rgb8; int32_t width, height; };
+struct Scene {
+    const float4 *n0, *n1;   // one float4 each per node (layout below)
+    // per primitive (Scene::add order), 32 bytes = one half cache line for a hit's two loads:
+    //   prims[2 i]     = (cx, cy, cz, bits(kind | (texture index + 1) << 2))
+    //   prims[2 i + 1] = its material's (albedo r, g, b, param); a Dielectric's: (schlick r0, 1 / ref_idx, -, ref_idx)
+    const float4 *prims;
+    const Texture *textures;
+    int32_t n_nodes, n_spheres;
+    int32_t root_code;       // node code of the root
+    int32_t lds_nodes;       // n0[0 .. lds_nodes) is staged in LDS by the path kernel
+    int32_t bounded;         // every sphere has |c_i| <= 2^32 and |r| <= 2^32 (see regular_ray)
+    // extension scenes only (pt_upload_scene_ext; DESIGN.md section 10)
+    const float4 *xforms;    // per transform: (offset.xyz, sin theta), (cos theta, -, -, -)
+    int32_t ext;             // 1: rendered by the extension's kernel instantiation
+};
+struct Camera {               // camera.rs:4-11
+    f3 llc, origin, horizontal, vertical;
+    int32_t width, height;
+};
+
 #define PTD __device__ __forceinline__
+
+// Everything below is arithmetic.  It exists in two builds that must never mix: the EXACT one (this
+// header as the library's translation units see it: every operation rounded once, in the reference's
+// order) and the FAST one (pt_kernels_fast.hip: contraction on, hardware reciprocal / square root
+// estimates, opt-in through pt_set_mode) -- hence the inline namespace, which keeps the two sets of
+// inline functions apart while the types above, which cross the launch interface, stay shared.
+#ifdef PT_FAST_MODE
+inline namespace fastmath {
+#else
+inline namespace exactmath {
+#endif
 
 PTD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PTD f3 fill(float v) { return mk(v, v, v); }                                     // vec.rs:79
@@ -27,6 +60,12 @@ PTD f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }       
 PTD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }        // vec.rs:169 (splat)
 PTD f3 neg(f3 a) { return a * -1.0f; }                                           // vec.rs:137-142
 PTD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }        // vec.rs:32-36,99-101
+// the same with contraction off whatever the build: three products and two sums, each rounded once
+PTD float dot_unfused(f3 a, f3 b)
+{
+#pragma clang fp contract(off)
+    return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
 // Short forms of the three unary IEEE operations on the path.  Each returns, bit for bit, what
 // the correctly rounded operation returns -- for EVERY fp32 input: inside the guard range one
 // hardware estimate (v_rcp_f32 / v_rsq_f32, 1 ulp) plus one fused correction step rounds
@@ -48,23 +87,50 @@ PTD float sqrt_core(float x)
     return __builtin_fmaf(d, h, g);
 }
 // 1.0f / x; guard |x| in [2^-95, 2^95]
-PTD float p_rcp(float x)
+PTD float x_rcp(float x)
 {
     if (__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 0x10000000u <= 0x5f000000u, 1)) return rcp_core(x);
     return 1.0f / x;
 }
 // sqrtf(x); guard x in [2^-95, FLT_MAX]
-PTD float p_sqrt(float x)
+PTD float x_sqrt(float x)
 {
     if (__builtin_expect(__float_as_uint(x) - 0x10000000u <= 0x6f7fffffu, 1)) return sqrt_core(x);
     return __builtin_sqrtf(x);
 }
 // P1: portable RSQ in place of _mm_rsqrt_ps (vec.rs:38-44): 1.0f / sqrtf(x), two roundings
-PTD float rsq(float x)
+PTD float x_rsq(float x)
 {
     if (__builtin_expect(__float_as_uint(x) - 0x10000000u <= 0x6f7fffffu, 1)) return rcp_core(sqrt_core(x));
     return 1.0f / __builtin_sqrtf(x);
 }
+#ifdef PT_FAST_MODE
+#ifndef PT_FAST_LEAF
+// Sphere::trace in the FAST build: 0 = exactly as in the EXACT build; 1 = b, c and the discriminant un-fused (they
+// cancel: their rounding decides grazing hits), roots through the sqrt estimate and * 1/a; 2 = everything fused.
+// Measured on the RTOW scene at 4096 spp, pixels within 1/255 of EXACT: 99.994 % / 99.995 % / 99.78 % -- with 2
+// the horizon of the r = 1000 ground sphere and every silhouette differ systematically, whatever the spp
+// (tools/fast_diag.py, tools/fast_where.py); 1 costs 2 % over 2.
+#define PT_FAST_LEAF 1
+#endif
+// FAST build (pt_set_mode(PT_FAST)): the hardware estimates as they are (1 ulp), no correction step
+PTD float p_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+PTD float p_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PTD float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+#if PT_FAST_LEAF == 0
+PTD float walk_rcp(float a) { return rcp_core(a); }
+PTD float leaf_sqrt(float x) { return x_sqrt(x); }
+#else
+PTD float walk_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+PTD float leaf_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#endif
+#else
+PTD float walk_rcp(float a) { return rcp_core(a); }   // RN(1 / dot(d, d)) for REGULAR rays (regular_ray)
+PTD float leaf_sqrt(float x) { return x_sqrt(x); }
+PTD float p_rcp(float x) { return x_rcp(x); }
+PTD float p_sqrt(float x) { return x_sqrt(x); }
+PTD float rsq(float x) { return x_rsq(x); }
+#endif
 PTD f3 normalized(f3 a) { return a * rsq(dot(a, a)); }                           // vec.rs:95-97
 
 // _mm_min_ps / _mm_max_ps lane semantics (vec.rs:50-51): second operand if either is NaN
@@ -182,32 +248,11 @@ PTD float p_asinf(float y)
     return (float)atan2_core(yd, c);
 }
 
-// ---- device scene -------------------------------------------------------------
-struct Texture { const uint8_t *rgb8; int32_t width, height; };
-struct Scene {
-    const float4 *n0, *n1;   // one float4 each per node (layout below)
-    // per primitive (Scene::add order), 32 bytes = one half cache line for a hit's two loads:
-    //   prims[2 i]     = (cx, cy, cz, bits(kind | (texture index + 1) << 2))
-    //   prims[2 i + 1] = its material's (albedo r, g, b, param); a Dielectric's: (schlick r0, 1 / ref_idx, -, ref_idx)
-    const float4 *prims;
-    const Texture *textures;
-    int32_t n_nodes, n_spheres;
-    int32_t root_code;       // node code of the root
-    int32_t lds_nodes;       // n0[0 .. lds_nodes) is staged in LDS by the path kernel
-    int32_t bounded;         // every sphere has |c_i| <= 2^32 and |r| <= 2^32 (see regular_ray)
-    // extension scenes only (pt_upload_scene_ext; DESIGN.md section 10)
-    const float4 *xforms;    // per transform: (offset.xyz, sin theta), (cos theta, -, -, -)
-    int32_t ext;             // 1: rendered by the extension's kernel instantiation
-};
-struct Camera {               // camera.rs:4-11
-    f3 llc, origin, horizontal, vertical;
-    int32_t width, height;
-};
-
 struct Ray { f3 o, d; };
 
 PTD Ray camera_ray(const Camera &c, float u, float v)                            // camera.rs:37-44
 {
+#pragma clang fp contract(off)   // also in the FAST build: primary rays are the reference's, bit for bit
     Ray r;
     r.o = c.origin;
     r.d = ((c.llc + c.horizontal * u) + c.vertical * v) - c.origin;
@@ -343,21 +388,51 @@ PTD int32_t split_step(const float4 n0, const float4 n1, const f3 o, const f3 in
     return (tmin < tmax) ? __float_as_int(n1.w) : __float_as_int(n0.w);
 }
 
+#ifdef PT_FAST_MODE
+// FAST build: the slab test with one fused multiply-add per plane, t = b * inv + (-(o * inv)), the product
+// o * inv taken once per walk (noi).  Not the reference's rounding: results are within the north-star
+// tolerance of it, not bit-equal (pt_set_mode).
+PTD int32_t split_step_fast(const float4 n0, const float4 n1, const f3 inv, const f3 noi, const float closest)
+{
+    const f3 v0 = mk(__builtin_fmaf(n0.x, inv.x, noi.x), __builtin_fmaf(n0.y, inv.y, noi.y), __builtin_fmaf(n0.z, inv.z, noi.z));
+    const f3 v1 = mk(__builtin_fmaf(n1.x, inv.x, noi.x), __builtin_fmaf(n1.y, inv.y, noi.y), __builtin_fmaf(n1.z, inv.z, noi.z));
+    const float tmin = vmed3(vmed3(vmed3(T_MIN, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
+    const float tmax = vmed3(vmed3(vmed3(closest, v0.x, v1.x), v0.y, v1.y), v0.z, v1.z);
+    return (tmin < tmax) ? __float_as_int(n1.w) : __float_as_int(n0.w);
+}
+#endif
+
 // Sphere::trace (sphere.rs:46-69) for the Leaf whose data is (n0, n1); `a` = dot(d, d)
 // FAST (wave-uniform; REGULAR rays only, see regular_ray): the divisions by a = dot(d, d) go
 // through div_by with ra = RN(1/a), computed once per walk.
 PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, const float a, const float ra, const bool FAST, Hit &h)
 {
+#if defined(PT_FAST_MODE) && PT_FAST_LEAF < 2
+#pragma clang fp contract(off)   // the discriminant cancels: its rounding decides grazing hits (horizon, silhouettes)
+#endif
     f3 oc = o - mk(n0.x, n0.y, n0.z);
+#if defined(PT_FAST_MODE) && PT_FAST_LEAF < 2
+    float b = dot_unfused(oc, d);
+    float c = dot_unfused(oc, oc) - n0.w;
+#else
     float b = dot(oc, d);
     float c = dot(oc, oc) - n0.w;
+#endif
     float disc = b * b - a * c;
     if (disc > 0.0f) {
-        float sq = p_sqrt(disc);
+        float sq = leaf_sqrt(disc);
+#if defined(PT_FAST_MODE) && PT_FAST_LEAF >= 1
+        float sol = (-b - sq) * ra;
+        (void)FAST;
+        if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
+        else {
+            sol = (-b + sq) * ra;
+#else
         float sol = FAST ? div_by(-b - sq, a, ra) : (-b - sq) / a;
         if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
         else {
             sol = FAST ? div_by(-b + sq, a, ra) : (-b + sq) / a;
+#endif
             if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
         }
     }
@@ -541,4 +616,5 @@ PTD f3 sky(const Ray &ray, f3 att)                                              
 }
 
 #undef PTD
+}  // inline namespace exactmath / fastmath
 }  // namespace ptd

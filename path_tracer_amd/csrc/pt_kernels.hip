@@ -12,6 +12,22 @@
 
 using namespace ptd;
 
+// This file is compiled twice: as itself (EXACT: every kernel of the library) and, through
+// pt_kernels_fast.hip, with PT_FAST_MODE defined and contraction on -- then only the path kernel of the
+// reference's scenes is built, behind ptk_fast::launch_path (pt_set_mode(PT_FAST)).
+#ifdef PT_FAST_MODE
+#ifndef PT_FAST_BOX
+#define PT_FAST_BOX 1                 // 1: the slab test with one fma per plane (split_run_regular_fast)
+#endif
+#ifndef PT_FAST_BOX_LIMIT
+#define PT_FAST_BOX_LIMIT 4096.0f     // largest |o * inv| a lane may have for its wave to use it: error <= 2^-12 in t
+#endif
+#define PTK ptk_fast
+#define path_kernel path_kernel_fast   // its own name in profiles
+#else
+#define PTK ptk
+#endif
+
 namespace {
 
 // A 64-lane wave covers `P = 64 / lanes` pixels (a tw x th tile) times `lanes`
@@ -160,6 +176,69 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
     return code;
 }
 
+#ifdef PT_FAST_MODE
+// The SPLIT run of the FAST build: one v_fma_f32 per plane (pt_device.hpp split_step_fast): 15 VALU per node.
+template <bool ALL_IN_LDS>
+__device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3 inv, const f3 noi, const float closest, const Scene &sc,
+                                                          const int n_split_end, const int keep)
+{
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const uint64_t b1 = (uint64_t)(uintptr_t)sc.n1, b0 = (uint64_t)(uintptr_t)sc.n0;
+    const v4u rs1 = {(uint32_t)b1, (uint32_t)(b1 >> 32) & 0xffffu, (uint32_t)(sc.n_nodes * 16), 0x00020000u};
+    const v4u rs0 = {(uint32_t)b0, (uint32_t)(b0 >> 32) & 0xffffu, (uint32_t)(sc.n_nodes * 16), 0x00020000u};
+    uint64_t save, cur; int cnt;
+#define PT_RUN_TEST_FAST \
+    "v_fma_f32 v48, v48, %[ix], %[nx]\n v_fma_f32 v49, v49, %[iy], %[ny]\n v_fma_f32 v50, v50, %[iz], %[nz]\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    "v_fma_f32 v52, v52, %[ix], %[nx]\n v_fma_f32 v53, v53, %[iy], %[ny]\n v_fma_f32 v54, v54, %[iz], %[nz]\n" \
+    "v_med3_f32 v56, v48, v52, %[tmin]\n v_med3_f32 v57, %[t], v48, v52\n" \
+    "v_med3_f32 v56, v56, v49, v53\n v_med3_f32 v57, v57, v49, v53\n" \
+    "v_med3_f32 v56, v56, v50, v54\n v_med3_f32 v57, v57, v50, v54\n" \
+    "v_cmp_lt_f32 vcc, v56, v57\n s_nop 1\n" \
+    "v_cndmask_b32 %[code], v51, v55, vcc\n" \
+    "v_cmp_gt_u32 vcc, %[nspl], %[code]\n" \
+    "s_bcnt1_i32_b64 %[cnt], vcc\n s_cmp_ge_i32 %[cnt], %[keep]\n s_cselect_b64 exec, vcc, 0\n"
+    if (ALL_IN_LDS) {
+        asm volatile("s_mov_b64 %[save], exec\n"
+                     ".LPTRUNF%=:\n"
+                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
+                     "ds_read_b128 v[48:51], %[code]\n"
+                     "s_waitcnt lgkmcnt(0)\n"
+                     PT_RUN_TEST_FAST
+                     "s_cbranch_execnz .LPTRUNF%=\n"
+                     "s_mov_b64 exec, %[save]\n"
+                     : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
+                     : [nx] "v"(noi.x), [ny] "v"(noi.y), [nz] "v"(noi.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
+                       [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep)
+                     : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+    } else {
+        asm volatile("s_mov_b64 %[save], exec\n"
+                     ".LPTRUNF%=:\n"
+                     "v_cmp_gt_u32 vcc, %[lim], %[code]\n"
+                     "s_mov_b64 %[cur], exec\n"
+                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
+                     "s_andn2_b64 exec, %[cur], vcc\n"
+                     "s_cbranch_execz .LPTNODEEPF%=\n"
+                     "buffer_load_dwordx4 v[48:51], %[code], %[rs0], 0 offen\n"
+                     ".LPTNODEEPF%=:\n"
+                     "s_and_b64 exec, %[cur], vcc\n"
+                     "ds_read_b128 v[48:51], %[code]\n"
+                     "s_mov_b64 exec, %[cur]\n"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+                     PT_RUN_TEST_FAST
+                     "s_cbranch_execnz .LPTRUNF%=\n"
+                     "s_mov_b64 exec, %[save]\n"
+                     : [code] "+v"(code), [save] "=&s"(save), [cur] "=&s"(cur), [cnt] "=&s"(cnt)
+                     : [nx] "v"(noi.x), [ny] "v"(noi.y), [nz] "v"(noi.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
+                       [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
+                       [lim] "s"(sc.lds_nodes << 4)
+                     : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+    }
+#undef PT_RUN_TEST_FAST
+    return code;
+}
+#endif
+
 // EXT: the instantiation for scenes uploaded with pt_upload_scene_ext (rects, instances, lights, integrator
 // options).  The reference's scenes always run EXT = false, whose code is unchanged.
 template <bool ALL_IN_LDS, bool EXT = false>
@@ -242,6 +321,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     const int32_t C_DONE = n_nodes + 1;
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
     f3 inv = fill(0.0f);
+#ifdef PT_FAST_MODE
+    f3 noi = fill(0.0f);          // -(o * inv), once per walk (split_step_fast)
+    bool fma_ok = true;
+#endif
     float a = 0.0f, ra = 0.0f;
     Hit h; h.t = T_MAX; h.prim = -1;
     int32_t code = C_DONE;
@@ -299,7 +382,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         if (new_walk) {
             inv = mk(p_rcp(ray.d.x), p_rcp(ray.d.y), p_rcp(ray.d.z));            // scene/mod.rs:31: (1,1,1) / dir
             a = dot(ray.d, ray.d);                                               // sphere.rs:49
-            ra = rcp_core(a);                                                    // read by REGULAR rays only
+            ra = walk_rcp(a);                                                    // read by REGULAR rays only
+#ifdef PT_FAST_MODE
+            // t = b * inv + noi carries the rounding error of o * inv, about 2^-24 |o * inv|: harmless unless a
+            // direction component is nearly zero.  A lane whose |o * inv| exceeds 2^PT_FAST_BOX_LOG2 keeps its
+            // wave on the exact (b - o) * inv test for this walk.
+            noi = neg(ray.o * inv);
+            fma_ok = __builtin_fmaxf(__builtin_fabsf(noi.x), __builtin_fmaxf(__builtin_fabsf(noi.y), __builtin_fabsf(noi.z))) <= PT_FAST_BOX_LIMIT;
+#endif
             regular = regular_ray(inv, ray.o, a, sc.bounded != 0);
             h.t = T_MAX; h.prim = -1;
             code = sc.root_code;
@@ -312,6 +402,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         // every ray of the wave REGULAR (pt_device.hpp)?  Re-evaluated once per SHADE step; a lane
         // whose irregular walk is over keeps the wave on the general slab test until its next walk
         const bool all_regular = __ballot(!regular) == 0ull;
+#ifdef PT_FAST_MODE
+        const bool all_fma_ok = __ballot(!fma_ok) == 0ull;
+#endif
         bool done = false;
         for (;;) {
             const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
@@ -325,7 +418,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
                 if ((uint32_t)code < (uint32_t)n_nodes) {
                     if (all_regular) {
-#ifndef PT_STATS
+#if defined(PT_FAST_MODE) && PT_FAST_BOX
+                        if (all_fma_ok) code = split_run_regular_fast<ALL_IN_LDS>(code, inv, noi, h.t, sc, n_nodes, keep);
+                        else code = split_run_regular<ALL_IN_LDS>(code, ray.o, inv, h.t, sc, n_nodes, keep);
+#elif !defined(PT_STATS)
                         code = split_run_regular<ALL_IN_LDS>(code, ray.o, inv, h.t, sc, n_nodes, keep);
 #else   // the same run in C++, with its step counters
                         for (;;) {
@@ -460,6 +556,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
   }
 }
 
+#ifndef PT_FAST_MODE   // everything from here to the launchers is built once, in the EXACT translation unit
 // K1: primitive id (and t) hit by the primary ray of one sample index.
 template <bool EXT>
 __global__ __launch_bounds__(64) void primary_hit_kernel(Scene sc, Camera cam, int S, int sample, int32_t *__restrict__ hit_id,
@@ -523,8 +620,10 @@ __global__ __launch_bounds__(256) void grid_selftest_kernel(unsigned long long *
     if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 
+#endif   // !PT_FAST_MODE
 }  // namespace
 
+#ifndef PT_FAST_MODE
 // pt_selftest_division: 64 operand pairs (x, a) per lane for Sphere::trace's division x / a through
 // ra = RN(1/a) (pt_device.hpp div_by, regular_ray): a over the whole REGULAR range [2^-32, 2^32]
 // with mantissas biased to the ends of the binade; x random (mode 0) or built so that x / a lies
@@ -571,16 +670,22 @@ __global__ __launch_bounds__(256) void division_selftest_kernel(unsigned long lo
     if (bad) atomicAdd(count, (unsigned long long)bad);
 }
 
+#endif   // !PT_FAST_MODE
+
 // Scratch of pt_render_device_static (include/pt_amd.h): the work-distribution words of one
 // path-kernel launch (SchedParams: 64 control words + one `done` word per 8x8 tile), for callers
 // that cannot allocate.  Each GPU the library runs on holds its own copy of this array until the
 // process ends; host code never uses the array's name as an address -- ptk::static_sched resolves the
 // device address once per device and the launches take that pointer like any other buffer.
+#ifndef PT_FAST_MODE
 constexpr int kStaticSchedTiles = 1 << 18;                  // 8x8 tiles: frames up to 16.7 M pixels (a 4K frame has 129,600)
 constexpr int kStaticSchedWords = 64 + kStaticSchedTiles;   // 1 MiB + 256 B
 static __device__ __align__(256) int32_t scratch[kStaticSchedWords];
+#endif   // !PT_FAST_MODE
 
-namespace ptk {
+namespace PTK {
+
+#ifndef PT_FAST_MODE
 
 // Device address and size of `scratch` on `device`, which must be the CURRENT device (pt_create
 // calls this right after hipSetDevice).  Resolved once per device and kept: every GPU holds its own
@@ -652,6 +757,10 @@ int tiles_for(const Camera &cam, int lanes)
 
 // control words + one `done` word per 8x8 tile (the only tiling that is split into pieces)
 size_t sched_bytes(const Camera &cam) { return (64 + (size_t)tiles_for(cam, 1)) * sizeof(int32_t); }
+#else
+using ptk::sched_bytes;
+using ptk::tiles_for;
+#endif   // !PT_FAST_MODE
 
 hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &rp, int32_t *d_sched, float *d_radiance,
                        hipStream_t stream)
@@ -684,11 +793,17 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
         if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
         else hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
     } else {
+#ifndef PT_FAST_MODE
         if (in_lds) hipLaunchKernelGGL((path_kernel<true, true>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
         else hipLaunchKernelGGL((path_kernel<false, true>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+#else
+        return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
+#endif
     }
     return hipGetLastError();
 }
+
+#ifndef PT_FAST_MODE
 
 hipError_t launch_primary_hits(const Scene &sc, const Camera &cam, int S, int sample, int32_t *d_hit_id, float *d_hit_t,
                                hipStream_t stream)
@@ -706,4 +821,6 @@ hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t 
     return hipGetLastError();
 }
 
-}  // namespace ptk
+#endif   // !PT_FAST_MODE
+
+}  // namespace PTK

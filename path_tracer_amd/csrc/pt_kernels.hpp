@@ -42,3 +42,9 @@ hipError_t launch_primary_hits(const ptd::Scene &sc, const ptd::Camera &cam, int
                                float *d_hit_t, hipStream_t stream);
 hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t *d_rgb8, hipStream_t stream);
 }  // namespace ptk
+
+// the FAST build of the path kernel (pt_kernels_fast.hip; reference scenes only)
+namespace ptk_fast {
+hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
+                       float *d_radiance, hipStream_t stream);
+}  // namespace ptk_fast

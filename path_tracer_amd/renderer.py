@@ -73,6 +73,11 @@ class ParallelRenderer:
     def set_lanes_per_pixel(self, lanes):
         _abi.check(self._ctx, _abi.lib().pt_set_lanes_per_pixel(self._ctx, int(lanes)))
 
+    def set_mode(self, fast):
+        """pt_set_mode: False = PT_EXACT (default, bit parity with the oracle), True = PT_FAST (fused arithmetic,
+        within the north-star tolerance)."""
+        _abi.check(self._ctx, _abi.lib().pt_set_mode(self._ctx, _abi.PT_FAST if fast else _abi.PT_EXACT))
+
     def lanes_per_pixel(self, samples, sample_begin, sample_end):
         return _abi.lib().pt_get_lanes_per_pixel(self._ctx, samples, sample_begin, sample_end)
 

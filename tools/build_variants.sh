@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../path_tracer_amd/csrc"
 mkdir -p ../../build/variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=default $flags -shared -o ../../build/variants/$name.so -x hip pt_api.cpp pt_group.cpp pt_host.cpp pt_kernels.hip -L/opt/rocm/lib -lrccl &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=default $flags -shared -o ../../build/variants/$name.so -x hip pt_api.cpp pt_group.cpp pt_host.cpp pt_kernels.hip pt_kernels_fast.hip -L/opt/rocm/lib -lrccl &
 done
 wait
 ls -la ../../build/variants
