@@ -195,6 +195,32 @@ float pt_last_path_kernel_ms(pt_context *ctx);
 enum { PT_EXACT = 0, PT_FAST = 1 };
 int pt_set_mode(pt_context *ctx, int32_t mode);
 
+/* Order in which the walk visits a Split's two children.  No counterpart in the reference, whose
+ * BvhNode::trace always enters the left child first (src/scene/bvh.rs:111-118).  The tree -- its boxes
+ * and leaves, caller-supplied or built here -- is never changed; only the threading of the device copy is.
+ *   PT_WALK_VIEW (default): the child whose box centre is nearer to the camera's origin first.  Primary
+ *            rays then find their closest hit early and the boxes behind it fail their test against it:
+ *            11 % fewer box tests and 16 % fewer sphere tests per path on the bench scene.  The node
+ *            arrays are re-threaded (host, O(nodes)) by pt_set_camera and pt_upload_scene.
+ *   PT_WALK_REFERENCE: left child first, the reference's own visiting order.
+ * A ray's closest hit does not depend on the order in which its candidates are found, so both orders
+ * return the same hit ids and the same radiance bit for bit (every parity test runs under PT_WALK_VIEW;
+ * tests/test_gpu_parity.py::test_walk_orders_agree compares the two).  Two fine points: (1) candidates with
+ * the SAME t -- two spheres of equal centre and squared radius, or a ray through the very circle where two
+ * overlapping spheres meet (seen about once in 10^8 primary rays on the bench scene) -- where the reference
+ * keeps the first one its walk meets (strict '<', src/traceable/sphere.rs:57): the device's leaves carry
+ * their rank in the reference's order and the lower rank wins a tie, which restores the reference's choice
+ * under any order; pt_upload_scene_ext scenes (coplanar rects tie by construction) are always walked in the
+ * reference's order, and so are trees in which some box does not contain what is below it (the reference
+ * builds such boxes for spheres of negative radius, src/traceable/sphere.rs:71-76: there a box test can hide
+ * a closer hit and the order decides) -- pt_get_walk_order reports the order in effect; (2) a root and a box-entry distance
+ * that agree to within an fp32 rounding error while a second hit lies within the same error of them --
+ * needs a hit on the very point where a sphere touches its box together with a near-tie; never observed
+ * (DESIGN.md section 11). */
+enum { PT_WALK_REFERENCE = 0, PT_WALK_VIEW = 1 };
+int pt_set_walk_order(pt_context *ctx, int32_t order);
+int pt_get_walk_order(const pt_context *ctx);   /* the order in effect for the uploaded scene */
+
 /* How a pixel's samples are spread over GPU lanes.  0 (default) = automatic:
  * one lane owns all samples of a pixel whenever the frame alone fills the GPU,
  * which reproduces the reference's sequential fp32 sum order (raytracer.rs:88)

@@ -18,6 +18,7 @@ PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 PT_DIFFUSE_LIGHT = 3                       # extension (include/pt_amd.h)
 PT_PRIM_SPHERE, PT_PRIM_RECT = 0, 1
 PT_EXACT, PT_FAST = 0, 1
+PT_WALK_REFERENCE, PT_WALK_VIEW = 0, 1
 
 
 class PtSphere(C.Structure):
@@ -83,6 +84,8 @@ SIGNATURES = {
     "pt_primary_hits_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_last_path_kernel_ms": (C.c_float, [C.c_void_p]),
     "pt_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pt_set_walk_order": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pt_get_walk_order": (C.c_int, [C.c_void_p]),
     "pt_set_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_selftest_unary": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),

@@ -3,6 +3,7 @@
 // and the kernels in pt_kernels.hip.  No exception leaves this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -83,6 +84,8 @@ void free_scene(pt_context *c)
 {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_prims) (void)hipFree(c->d_prims);
+    if (c->d_prim_ids) (void)hipFree(c->d_prim_ids);
+    c->d_prim_ids = nullptr;
     if (c->d_textures) (void)hipFree(c->d_textures);
     if (c->d_xforms) (void)hipFree(c->d_xforms);
     for (uint8_t *p : c->d_texels) (void)hipFree(p);
@@ -111,6 +114,171 @@ int check_ready(pt_context *c, int32_t samples)
     // samples == 1 divides 0/0 in the reference's grid (raytracer.rs:78): refuse it
     if (samples < 2) return fail(c, PT_ERR_INVALID, "samples must be >= 2 (got %d)", samples);
     if (samples > 1024) return fail(c, PT_ERR_LIMIT, "samples must be <= 1024 (got %d)", samples);
+    return PT_OK;
+}
+
+// Does every Split's box contain the boxes of its two children, and every sphere's box (centre -+ |radius|) its
+// sphere?  "The order of the walk does not change a ray's closest hit" rests on it: a box that does not
+// contain what is below it can hide a closer hit behind a farther one found earlier, and then the order matters.
+// The reference builds such boxes for spheres of NEGATIVE radius (Sphere::bounding_box is centre -+ radius as
+// written, so min and max swap: the hollow-glass idiom); a caller's tree may hold anything.
+bool boxes_contain(const pt_bvh_node *nodes, int32_t n_nodes, const pt_primitive *prims)
+{
+    auto inside = [](const float *lo, const float *hi, const float *plo, const float *phi) {
+        for (int k = 0; k < 3; k++)
+            if (!(plo[k] <= lo[k] && hi[k] <= phi[k])) return false;   // NaN fails
+        return true;
+    };
+    for (int32_t i = 0; i < n_nodes; i++) {
+        if (nodes[i].prim >= 0) continue;
+        const int32_t kids[2] = {i + 1, nodes[i + 1].skip};
+        for (int32_t kid : kids) {
+            float lo[3], hi[3];
+            if (nodes[kid].prim >= 0) {
+                const pt_primitive &p = prims[nodes[kid].prim];
+                if (p.kind != PT_PRIM_SPHERE) return false;
+                const float r = std::fabs(p.v[3]);
+                for (int k = 0; k < 3; k++) { lo[k] = p.v[k] - r; hi[k] = p.v[k] + r; }
+            } else {
+                for (int k = 0; k < 3; k++) { lo[k] = nodes[kid].bmin[k]; hi[k] = nodes[kid].bmax[k]; }
+            }
+            if (!inside(lo, hi, nodes[i].bmin, nodes[i].bmax)) return false;
+        }
+    }
+    return true;
+}
+
+// Lays the context's tree (c->h_tree, DFS pre-order as uploaded) out in the device node arrays and threads it:
+// every node gets the code of the node the walk visits next (`next`: a Split's first child, a Leaf's
+// successor) and a Split the code of the node that follows its subtree (`skip`).  The TREE is the
+// caller's -- same boxes, same leaves -- and so is the set of tests a ray can make; what this function chooses
+// is which of a Split's two children the walk enters first:
+//   PT_WALK_REFERENCE  the left one (bvh.rs:111-118), the reference's order;
+//   PT_WALK_VIEW       the one whose box centre is nearer to the camera's origin.  Primary rays then find
+//                      their closest hit early and skip what lies behind it; rays from elsewhere are served
+//                      no worse than by the left-first order (-11 % box tests, -16 %
+//                      sphere tests per path on the bench scene).
+// The closest hit of a ray does not depend on the order in which its candidates are found -- except
+// among candidates with the SAME t, where the reference keeps the one its walk meets first (strict '<',
+// sphere.rs:57).  Leaves therefore carry their RANK in the reference's order (= the primitive's index in
+// the device arrays, upload_common), and Sphere::trace on the device lets the lower rank win a tie
+// (pt_device.hpp closer): in the reference's order that never fires, in any other order it restores the
+// reference's choice.  Extension scenes (coplanar rects tie by construction, and rect_step has no such
+// rule) always keep the reference's order, and so do trees whose boxes do not contain what is below them
+// (boxes_contain): there a box test can hide a closer hit and the order of the walk decides which.
+// Slots: the first kMaxLdsNodes nodes breadth-first (the top of the tree -- visited by every ray -- is the prefix
+// the path kernel keeps in LDS), the others in walk order (a Split's first child is the next entry: neighbouring
+// entries share cache lines; -0.8 % on cfg 5 against breadth-first throughout).
+int thread_nodes(pt_context *c)
+{
+    const int32_t n_nodes = (int32_t)c->h_tree.size();
+    const pt_bvh_node *nodes = c->h_tree.data();
+    const bool view = c->walk_order == PT_WALK_VIEW && c->view_ok && c->have_camera;
+    const float eye[3] = {c->camera.origin.x, c->camera.origin.y, c->camera.origin.z};
+    if (c->threaded && c->threaded_view == view && (!view || std::memcmp(eye, c->threaded_eye, sizeof eye) == 0)) return PT_OK;
+
+    std::vector<int32_t> slot, order, first, second, succ, walk, stack;
+    std::vector<float4> h_nodes;
+    try {
+        slot.resize((size_t)n_nodes);
+        order.reserve((size_t)n_nodes);
+        first.assign((size_t)n_nodes, -1);
+        second.assign((size_t)n_nodes, -1);
+        succ.assign((size_t)n_nodes, n_nodes);
+        walk.reserve((size_t)n_nodes);
+        stack.reserve(64);
+        h_nodes.resize(2 * (size_t)n_nodes);
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
+    }
+    // squared distance from the eye to the centre of node i's box (a Leaf: its sphere's centre; the bounds of
+    // a Leaf are never read, include/pt_amd.h).  Host-side double arithmetic: it orders visits, it is not
+    // part of any result.
+    auto dist2 = [&](int32_t i) -> double {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const float4 &leaf = c->h_leaf[2 * (size_t)i];
+            const float lc[3] = {leaf.x, leaf.y, leaf.z};
+            const double centre = nodes[i].prim >= 0 ? (double)lc[k] : 0.5 * ((double)nodes[i].bmin[k] + (double)nodes[i].bmax[k]);
+            d2 += (centre - (double)eye[k]) * (centre - (double)eye[k]);
+        }
+        return d2;
+    };
+    for (int32_t i = 0; i < n_nodes; i++) {
+        if (nodes[i].prim >= 0) continue;
+        const int32_t l = i + 1, r = nodes[i + 1].skip;
+        const bool swap = view && dist2(r) < dist2(l);   // NaN compares false: left first
+        first[i] = swap ? r : l;
+        second[i] = swap ? l : r;
+    }
+    // walk order (depth-first, first child before second) and every node's successor
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int32_t i = stack.back();
+        stack.pop_back();
+        walk.push_back(i);
+        if (nodes[i].prim < 0) {
+            succ[first[i]] = second[i];
+            succ[second[i]] = succ[i];
+            stack.push_back(second[i]);
+            stack.push_back(first[i]);
+        }
+    }
+    if ((int32_t)walk.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
+    order.push_back(0);
+    for (size_t q = 0; q < order.size() && order.size() < (size_t)n_nodes; q++) {
+        const int32_t i = order[q];
+        if (nodes[i].prim < 0) {
+            order.push_back(first[i]);
+            order.push_back(second[i]);
+        }
+    }
+    if ((int32_t)order.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
+    if (n_nodes <= kMaxLdsNodes) {
+        for (int32_t q = 0; q < n_nodes; q++) slot[order[q]] = q;
+    } else {
+        std::vector<char> in_prefix;
+        try {
+            in_prefix.assign((size_t)n_nodes, 0);
+        } catch (...) {
+            return fail(c, PT_ERR_INVALID, "out of host memory");
+        }
+        for (int32_t q = 0; q < kMaxLdsNodes; q++) { slot[order[q]] = q; in_prefix[order[q]] = 1; }
+        int32_t next_slot = kMaxLdsNodes;
+        for (int32_t i : walk)
+            if (!in_prefix[i]) slot[i] = next_slot++;
+    }
+    // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
+    auto code_of = [&](int32_t i) -> int32_t {
+        if (i >= n_nodes) return n_nodes << PT_CODE_SHIFT;
+        return nodes[i].prim >= 0 ? (int32_t)((uint32_t)(slot[i] << PT_CODE_SHIFT) | 0x80000000u) : (slot[i] << PT_CODE_SHIFT);
+    };
+    float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_nodes;
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const pt_bvh_node &nd = nodes[i];
+        float4 a, b;
+        if (nd.prim < 0) {
+            const int32_t skip = code_of(succ[i]), next = code_of(first[i]);
+            a = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], 0.0f);
+            b = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.0f);
+            std::memcpy(&a.w, &skip, 4);
+            std::memcpy(&b.w, &next, 4);
+        } else {
+            const int32_t next = code_of(succ[i]);
+            a = c->h_leaf[2 * (size_t)i];
+            b = c->h_leaf[2 * (size_t)i + 1];
+            std::memcpy(&b.w, &next, 4);
+        }
+        h_n0[slot[i]] = a;
+        h_n1[slot[i]] = b;
+    }
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipDeviceSynchronize());   // launches on caller streams (pt_render_device) may still be walking the old arrays
+    PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->scene.root_code = code_of(0);
+    c->threaded = true;
+    c->threaded_view = view;
+    std::memcpy(c->threaded_eye, eye, sizeof eye);
     return PT_OK;
 }
 
@@ -262,79 +430,58 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
             return fail(c, PT_ERR_INVALID, "node %d: children do not tile its subtree", i);
     }
 
-    // Device layout (pt_device.hpp).  Nodes are renumbered breadth-first (the first kMaxLdsNodes of them) so that the
-    // top of the tree -- visited by every ray -- is the prefix the path kernel keeps
-    // in LDS; the walk order is unchanged, it follows the explicit next/skip codes.
-    std::vector<int32_t> slot, order;
-    std::vector<float4> h_nodes, h_prims, h_xforms;
+    // Rank of every primitive = position of its Leaf in the tree's depth-first order = the order in which the
+    // reference's walk meets the primitives (bvh.rs:106-127).  The device arrays hold the primitives BY RANK, so
+    // a hit's primitive index doubles as the tie-break key of pt_device.hpp closer(); prim_ids maps back to the
+    // caller's ids (hit-id AOV).
+    std::vector<int32_t> rank_of, prim_ids;
     try {
-        slot.resize((size_t)n_nodes);
-        order.reserve((size_t)n_nodes);
-        h_nodes.resize(2 * (size_t)n_nodes);
+        rank_of.assign((size_t)n_prims, -1);
+        prim_ids.reserve((size_t)n_prims);
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
+    }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const int32_t pr = nodes[i].prim;
+        if (pr < 0) continue;
+        if (rank_of[pr] >= 0) return fail(c, PT_ERR_INVALID, "node %d: primitive %d already has a leaf", i, pr);
+        rank_of[pr] = (int32_t)prim_ids.size();
+        prim_ids.push_back(pr);
+    }
+    if ((int32_t)prim_ids.size() != n_prims) return fail(c, PT_ERR_INVALID, "the tree has %d leaves for %d primitives", (int32_t)prim_ids.size(), n_prims);
+
+    // Host copy of the tree and of its leaves' device records: the node arrays are laid out and threaded
+    // by thread_nodes, again whenever the camera or the walk order changes.
+    // a rect's flags (pt_device.hpp rect_step): bit 0 = rect, bits 1-2 = axis, bit 3 = flip, bits 4.. = transform + 1
+    auto rect_flags = [](const pt_primitive &p) -> int32_t { return 1 | (p.axis << 1) | ((p.flip ? 1 : 0) << 3) | ((p.transform + 1) << 4); };
+    std::vector<pt_bvh_node> h_tree;
+    std::vector<float4> h_leaf, h_prims, h_xforms;
+    try {
+        h_tree.assign(nodes, nodes + n_nodes);
+        h_leaf.assign(2 * (size_t)n_nodes, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         h_prims.resize(2 * (size_t)n_prims);
         h_xforms.resize(2 * (size_t)(n_xforms > 0 ? n_xforms : 0));
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
-    order.push_back(0);
-    for (size_t q = 0; q < order.size(); q++) {
-        const int32_t i = order[q];
-        slot[i] = (int32_t)q;
-        if (nodes[i].prim < 0) {
-            if (order.size() + 2 > (size_t)n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");   // stays within the reservation
-            order.push_back(i + 1);
-            order.push_back(nodes[i + 1].skip);
-        }
-    }
-    if ((int32_t)order.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
-    // Beyond the LDS prefix the nodes go back to the tree's own depth-first order: a walk that
-    // descends below the prefix then reads neighbouring entries (a Split's first child is the next
-    // node), which share cache lines; breadth-first order scatters them (-0.8 % on cfg 5).
-    if (n_nodes > kMaxLdsNodes) {
-        std::vector<char> in_prefix;
-        try {
-            in_prefix.assign((size_t)n_nodes, 0);
-        } catch (...) {
-            return fail(c, PT_ERR_INVALID, "out of host memory");
-        }
-        for (int32_t q = 0; q < kMaxLdsNodes; q++) in_prefix[order[q]] = 1;
-        int32_t next_slot = kMaxLdsNodes;
-        for (int32_t i = 0; i < n_nodes; i++)
-            if (!in_prefix[i]) slot[i] = next_slot++;
-    }
-    // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
-    auto code_of = [&](int32_t i) -> int32_t {
-        if (i >= n_nodes) return n_nodes << PT_CODE_SHIFT;
-        return nodes[i].prim >= 0 ? (int32_t)((uint32_t)(slot[i] << PT_CODE_SHIFT) | 0x80000000u) : (slot[i] << PT_CODE_SHIFT);
-    };
-    // a rect's flags (pt_device.hpp rect_step): bit 0 = rect, bits 1-2 = axis, bit 3 = flip, bits 4.. = transform + 1
-    auto rect_flags = [](const pt_primitive &p) -> int32_t { return 1 | (p.axis << 1) | ((p.flip ? 1 : 0) << 3) | ((p.transform + 1) << 4); };
-    float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_nodes;
     for (int32_t i = 0; i < n_nodes; i++) {
         const pt_bvh_node &nd = nodes[i];
+        if (nd.prim < 0) continue;
         float4 a, b;
-        const int32_t next = code_of(i + 1);
-        if (nd.prim < 0) {
-            const int32_t skip = code_of(nd.skip);
-            a = make_float4(nd.bmin[0], nd.bmin[1], nd.bmin[2], 0.0f);
-            b = make_float4(nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.0f);
-            std::memcpy(&a.w, &skip, 4);
-        } else if (prims[nd.prim].kind == PT_PRIM_RECT) {
+        if (prims[nd.prim].kind == PT_PRIM_RECT) {
             const pt_primitive &r = prims[nd.prim];
             const int32_t flags = rect_flags(r);
             a = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
             b = make_float4(r.v[4], 0.0f, 0.0f, 0.0f);
             std::memcpy(&b.y, &flags, 4);
-            std::memcpy(&b.z, &nd.prim, 4);
         } else {
             const pt_primitive &s = prims[nd.prim];
             a = make_float4(s.v[0], s.v[1], s.v[2], s.v[3] * s.v[3]);   // sphere.rs:51: radius * radius, one fp32 multiply
             b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            std::memcpy(&b.z, &nd.prim, 4);
         }
-        std::memcpy(&b.w, &next, 4);
-        h_n0[slot[i]] = a;
-        h_n1[slot[i]] = b;
+        std::memcpy(&b.z, &rank_of[nd.prim], 4);
+        h_leaf[2 * (size_t)i] = a;
+        h_leaf[2 * (size_t)i + 1] = b;
     }
     for (int32_t i = 0; i < n_prims; i++) {
         const pt_primitive &p = prims[i];
@@ -349,11 +496,12 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
             tag |= 1 << 30;
         }
         std::memcpy(&a.w, &tag, 4);
-        h_prims[2 * (size_t)i] = a;
-        h_prims[2 * (size_t)i + 1] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
+        const size_t at = 2 * (size_t)rank_of[i];
+        h_prims[at] = a;
+        h_prims[at + 1] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
         // a Dielectric has no albedo: the slots carry the two values its scatter derives from ref_idx
         // alone, math/mod.rs:37-38 and dielectric.rs:41, computed here with the same fp32 operations
-        if (m.kind == PT_DIELECTRIC) h_prims[2 * (size_t)i + 1] = make_float4(ptd::schlick_r0(m.param), 1.0f / m.param, 0.0f, m.param);
+        if (m.kind == PT_DIELECTRIC) h_prims[at + 1] = make_float4(ptd::schlick_r0(m.param), 1.0f / m.param, 0.0f, m.param);
     }
     for (int32_t i = 0; i < n_xforms; i++) {
         h_xforms[2 * (size_t)i] = make_float4(xforms[i].offset[0], xforms[i].offset[1], xforms[i].offset[2], xforms[i].sin_theta);
@@ -363,10 +511,11 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     free_scene(c);
-    PT_HIP(c, hipMalloc((void **)&c->d_nodes, h_nodes.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_nodes, 2 * (size_t)n_nodes * sizeof(float4)));
     PT_HIP(c, hipMalloc((void **)&c->d_prims, h_prims.size() * sizeof(float4)));
-    PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_prims, h_prims.data(), h_prims.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMalloc((void **)&c->d_prim_ids, prim_ids.size() * sizeof(int32_t)));
+    PT_HIP(c, hipMemcpy(c->d_prim_ids, prim_ids.data(), prim_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!h_xforms.empty()) {
         PT_HIP(c, hipMalloc((void **)&c->d_xforms, h_xforms.size() * sizeof(float4)));
         PT_HIP(c, hipMemcpy(c->d_xforms, h_xforms.data(), h_xforms.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -395,12 +544,12 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     c->scene.n0 = c->d_nodes;
     c->scene.n1 = c->d_nodes + n_nodes;
     c->scene.prims = c->d_prims;
+    c->scene.prim_ids = c->d_prim_ids;
     c->scene.textures = c->d_textures;
     c->scene.xforms = c->d_xforms;
     c->scene.ext = ext ? 1 : 0;
     c->scene.n_nodes = n_nodes;
     c->scene.n_spheres = n_prims;
-    c->scene.root_code = code_of(0);
     c->scene.lds_nodes = n_nodes < kMaxLdsNodes ? n_nodes : kMaxLdsNodes;
     // regular_ray (pt_device.hpp): the short division needs every sphere inside 2^32 (NaN fails the test)
     bool bounded = true;
@@ -411,6 +560,13 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
         bounded = bounded && std::fabs(v[0]) <= lim && std::fabs(v[1]) <= lim && std::fabs(v[2]) <= lim && std::fabs(v[3]) <= lim;
     }
     c->scene.bounded = bounded ? 1 : 0;
+    // PT_WALK_VIEW (thread_nodes): not for the extension's scenes, not for trees whose boxes do not contain their contents
+    c->view_ok = !ext && boxes_contain(nodes, n_nodes, prims);
+    c->h_tree.swap(h_tree);
+    c->h_leaf.swap(h_leaf);
+    c->threaded = false;
+    const int rc = thread_nodes(c);
+    if (rc != PT_OK) return rc;
     c->have_scene = true;
     return PT_OK;
 }
@@ -512,6 +668,7 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
     }
     c->camera = next;
     c->have_camera = true;
+    if (c->have_scene) return thread_nodes(c);   // PT_WALK_VIEW orders the walk by the camera's origin
     return PT_OK;
 }
 
@@ -585,6 +742,23 @@ int pt_set_mode(pt_context *c, int32_t mode)
     if (mode != PT_EXACT && mode != PT_FAST) return fail(c, PT_ERR_INVALID, "mode must be PT_EXACT (0) or PT_FAST (1), got %d", mode);
     c->mode = mode;
     return PT_OK;
+}
+
+int pt_set_walk_order(pt_context *c, int32_t order)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (order != PT_WALK_REFERENCE && order != PT_WALK_VIEW)
+        return fail(c, PT_ERR_INVALID, "walk order must be PT_WALK_REFERENCE (0) or PT_WALK_VIEW (1), got %d", order);
+    c->walk_order = order;
+    if (c->have_scene) return thread_nodes(c);
+    return PT_OK;
+}
+
+int pt_get_walk_order(const pt_context *c)
+{
+    if (!c) return PT_ERR_INVALID;
+    if (!c->have_scene) return c->walk_order;
+    return c->threaded_view ? PT_WALK_VIEW : PT_WALK_REFERENCE;
 }
 
 int pt_get_lanes_per_pixel(const pt_context *c, int32_t samples, int32_t sample_begin, int32_t sample_end)

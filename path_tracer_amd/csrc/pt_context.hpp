@@ -19,6 +19,7 @@ struct pt_context {
     // device scene
     float4 *d_nodes = nullptr;
     float4 *d_prims = nullptr;
+    int32_t *d_prim_ids = nullptr;   // caller's primitive id per device index (= rank in the reference's walk order)
     float4 *d_xforms = nullptr;      // extension scenes: two float4 per pt_transform
     ptd::Texture *d_textures = nullptr;
     std::vector<uint8_t *> d_texels;
@@ -38,6 +39,15 @@ struct pt_context {
 
     int32_t lanes_override = 0;
     int32_t mode = PT_EXACT;      // pt_set_mode
+
+    // the uploaded tree (DFS pre-order, validated) and its leaves' device records (two float4 per node), kept so
+    // that the node arrays can be threaded again when the camera or the walk order changes (pt_api.cpp thread_nodes)
+    std::vector<pt_bvh_node> h_tree;
+    std::vector<float4> h_leaf;
+    int32_t walk_order = PT_WALK_VIEW;   // pt_set_walk_order
+    bool view_ok = false;                // not an extension scene
+    bool threaded = false, threaded_view = false;   // what d_nodes holds now
+    float threaded_eye[3] = {0.0f, 0.0f, 0.0f};
 
     int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
     size_t sched_bytes = 0;

@@ -19,10 +19,12 @@ struct f3 { float x, y, z; };
 struct Texture { const uint8_t *rgb8; int32_t width, height; };
 struct Scene {
     const float4 *n0, *n1;   // one float4 each per node (layout below)
-    // per primitive (Scene::add order), 32 bytes = one half cache line for a hit's two loads:
+    // per primitive, 32 bytes = one half cache line for a hit's two loads; i = the primitive's RANK in the
+    // reference's walk order (position of its Leaf in the tree's depth-first order), prim_ids[i] = the caller's id:
     //   prims[2 i]     = (cx, cy, cz, bits(kind | (texture index + 1) << 2))
     //   prims[2 i + 1] = its material's (albedo r, g, b, param); a Dielectric's: (schlick r0, 1 / ref_idx, -, ref_idx)
     const float4 *prims;
+    const int32_t *prim_ids;
     const Texture *textures;
     int32_t n_nodes, n_spheres;
     int32_t root_code;       // node code of the root
@@ -343,7 +345,16 @@ constexpr float T_MIN = 0.001f;                                                 
 constexpr float T_MAX = 3.402823466e+38f;                                        // f32::MAX, scene/mod.rs:27
 constexpr int32_t LEAF_BIT = (int32_t)0x80000000;
 
-struct Hit { float t; int32_t prim; };
+struct Hit { float t; int32_t prim; };   // prim: device index = rank in the reference's walk order, -1 = none
+
+// The acceptance test of Sphere::trace (sphere.rs:57,63: t < max_t && t > min_t) for a root of the primitive
+// of rank `rank`, given the closest hit so far.  The reference walks the primitives in rank order and keeps
+// the first of two equal roots (strict '<'); a walk in another order (PT_WALK_VIEW) reaches the same choice by
+// letting the lower rank win a tie.  In rank order the tie clause never fires: ranks only grow along the walk.
+PTD bool closer(float sol, int32_t rank, const Hit &h)
+{
+    return (sol < h.t || (sol == h.t && rank < h.prim)) && sol > T_MIN;
+}
 
 // codes count in units of 2^-PT_CODE_SHIFT slots: 4 = byte offsets (no shift per node visit)
 #ifndef PT_CODE_SHIFT
@@ -402,10 +413,28 @@ PTD int32_t split_step_fast(const float4 n0, const float4 n1, const f3 inv, cons
 }
 #endif
 
-// Sphere::trace (sphere.rs:46-69) for the Leaf whose data is (n0, n1); `a` = dot(d, d)
+// Sphere::trace (sphere.rs:46-69) for the Leaf whose data is (n0, n1); `a` = dot(d, d).
 // FAST (wave-uniform; REGULAR rays only, see regular_ray): the divisions by a = dot(d, d) go
 // through div_by with ra = RN(1/a), computed once per walk.
-PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, const float a, const float ra, const bool FAST, Hit &h)
+//
+// In two parts, because the two halves of a Leaf arrive at different times (n0 from LDS, n1 -- rank and next
+// code -- through the L1, several hundred cycles later under load: a Leaf step that reads n1 before its
+// arithmetic is done stalls on it, +14 % on the whole kernel):
+//   leaf_candidate  everything that needs n0 only: the root this sphere offers against the closest hit so
+//                   far, and whether the reference's test accepts it outright (`sure`) or it exactly TIES
+//                   the closest hit (`maybe`);
+//   leaf_accept     with n1: a tie goes to the lower rank (see closer()), then the hit is updated.
+// sphere.rs:55-66 with closer()'s tie rule, case by case (h.t > T_MIN always, so a tie is in range):
+//   first root r1:  r1 < h.t and r1 > T_MIN -> sure;  r1 == h.t -> maybe (then the second root, r2 >= r1 = h.t,
+//                   can only tie as well, with the same rank comparison: nothing more to try);
+//   otherwise r2:   r2 < h.t and r2 > T_MIN -> sure;  r2 == h.t -> maybe.
+// Written flat: the two roots are computed under their conditions, every comparison is made where all the
+// lanes of the step are active again, so that each flag is a lane mask in scalar registers, combined by scalar
+// instructions (a flag that crosses the end of a branch becomes a 0/1 vector register instead, with vector
+// instructions to pack and unpack it: +3.5 % on the whole kernel).  The tie rule costs three compares per Leaf
+// step: two `==` here, the rank comparison in leaf_accept.
+struct LeafCandidate { float t; bool sure, tie; };
+PTD LeafCandidate leaf_candidate(const float4 n0, const f3 o, const f3 d, const float a, const float ra, const bool FAST, const float closest)
 {
 #if defined(PT_FAST_MODE) && PT_FAST_LEAF < 2
 #pragma clang fp contract(off)   // the discriminant cancels: its rounding decides grazing hits (horizon, silhouettes)
@@ -418,24 +447,49 @@ PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, con
     float b = dot(oc, d);
     float c = dot(oc, oc) - n0.w;
 #endif
-    float disc = b * b - a * c;
-    if (disc > 0.0f) {
-        float sq = leaf_sqrt(disc);
+    const float disc = b * b - a * c;
+    const bool hit = disc > 0.0f;
+    float sq = 0.0f, sol1 = 0.0f, sol2 = 0.0f;
+    if (hit) {
+        sq = leaf_sqrt(disc);
 #if defined(PT_FAST_MODE) && PT_FAST_LEAF >= 1
-        float sol = (-b - sq) * ra;
         (void)FAST;
-        if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
-        else {
-            sol = (-b + sq) * ra;
+        sol1 = (-b - sq) * ra;
 #else
-        float sol = FAST ? div_by(-b - sq, a, ra) : (-b - sq) / a;
-        if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
-        else {
-            sol = FAST ? div_by(-b + sq, a, ra) : (-b + sq) / a;
+        sol1 = FAST ? div_by(-b - sq, a, ra) : (-b - sq) / a;
 #endif
-            if (sol < h.t && sol > T_MIN) { h.t = sol; h.prim = __float_as_int(n1.z); }
-        }
     }
+    const bool first = (bool)((int)hit & (int)(sol1 < closest) & (int)(sol1 > T_MIN));
+    const bool need2 = (bool)((int)hit & (int)!first);
+    if (need2) {
+#if defined(PT_FAST_MODE) && PT_FAST_LEAF >= 1
+        sol2 = (-b + sq) * ra;
+#else
+        sol2 = FAST ? div_by(-b + sq, a, ra) : (-b + sq) / a;
+#endif
+    }
+    LeafCandidate k;
+    k.sure = (bool)((int)first | ((int)need2 & (int)(sol2 < closest) & (int)(sol2 > T_MIN)));
+#ifndef PT_NO_TIE   // (PT_NO_TIE: measurement builds only -- ties go to the walk's first candidate)
+    // a first root that ties is followed by a second one >= it, which can only tie as well: either way the lane
+    // offers `closest` itself (h.t stays as it is) and the rank decides
+    k.tie = (bool)((int)need2 & ((int)(sol1 == closest) | (int)(sol2 == closest)));
+#else
+    k.tie = false;
+#endif
+    k.t = first ? sol1 : sol2;
+    return k;
+}
+PTD void leaf_accept(const LeafCandidate k, const float4 n1, Hit &h)
+{
+    const int32_t rank = __float_as_int(n1.z);
+    const bool take = (bool)((int)k.sure | ((int)k.tie & (int)(rank < h.prim)));
+    h.t = k.sure ? k.t : h.t;
+    h.prim = take ? rank : h.prim;
+}
+PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, const float a, const float ra, const bool FAST, Hit &h)
+{
+    leaf_accept(leaf_candidate(n0, o, d, a, ra, FAST, h.t), n1, h);
 }
 
 // ---- extension: rects and Translate(RotateY(..)) instances (NOT in the reference) ----------

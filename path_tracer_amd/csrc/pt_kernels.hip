@@ -100,6 +100,17 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #define PT_WAVES_PER_GROUP 4
 #endif
 constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
+// PT_LDS_BOTH (measurement; off): a tree that fits the LDS prefix keeps BOTH halves of its nodes in LDS (n1[] at
+// byte offset PT_LDS_N1_OFFSET of the group's allocation), so that a node visit costs no L1 access at all.  Slower:
+// 32 KiB per group needs groups of 8 waves to keep 8 waves per SIMD, and at that group size two LDS reads per
+// node take 545 ms against 497 ms for one LDS read + one L1 read (441 ms-equivalent build; groups of 4: 718 ms,
+// of 16: 613 ms): LDS bandwidth, not the L1, is the scarcer of the two.
+#ifndef PT_LDS_BOTH
+#define PT_LDS_BOTH 0
+#endif
+#define PT_LDS_N1_OFFSET 16384   // = 16 * kMaxLdsNodes (pt_api.cpp)
+#define PT_STR2(x) #x
+#define PT_STR(x) PT_STR2(x)
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 8   // waves per SIMD the register allocator must leave room for (64 VGPRs)
 #endif
@@ -123,44 +134,74 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
     const v4u rs1 = {(uint32_t)b1, (uint32_t)(b1 >> 32) & 0xffffu, (uint32_t)(sc.n_nodes * 16), 0x00020000u};
     const v4u rs0 = {(uint32_t)b0, (uint32_t)(b0 >> 32) & 0xffffu, (uint32_t)(sc.n_nodes * 16), 0x00020000u};
     uint64_t save, cur; int cnt;
+// Scratch registers of the run: A = n0 (v48-51), B = n1 (v52-55), E / F = the tmin / tmax chains (v56, v57).
+// Each pair (n0.k, n1.k) shares a VGPR bank (register number mod 4); a layout in which no instruction reads two
+// scratch registers of one bank (A = v46-49, B = v52-55, E = v51, F = v57, chains y, x, z) measured the same
+// (520.6 vs 521.0 ms): operand banks do not limit this loop.
+#define RA0 "v48"
+#define RA1 "v49"
+#define RA2 "v50"
+#define RA3 "v51"
+#define RA "v[48:51]"
+#define RB0 "v52"
+#define RB1 "v53"
+#define RB2 "v54"
+#define RB3 "v55"
+#define RB "v[52:55]"
+#define RE "v56"
+#define RF "v57"
+#define PT_RUN_CLOBBERS "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57"
+#define PT_RUN_CHAINS \
+    "v_med3_f32 " RE ", " RA0 ", " RB0 ", %[tmin]\n v_med3_f32 " RF ", %[t], " RA0 ", " RB0 "\n" \
+    "v_med3_f32 " RE ", " RE ", " RA1 ", " RB1 "\n v_med3_f32 " RF ", " RF ", " RA1 ", " RB1 "\n" \
+    "v_med3_f32 " RE ", " RE ", " RA2 ", " RB2 "\n v_med3_f32 " RF ", " RF ", " RA2 ", " RB2 "\n"
+#if PT_LDS_BOTH
+#define PT_RUN_WAIT_B "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+#else
+#define PT_RUN_WAIT_B "s_waitcnt vmcnt(0)\n"
+#endif
 #define PT_RUN_TEST \
-    "v_sub_f32 v48, v48, %[ox]\n v_sub_f32 v49, v49, %[oy]\n v_sub_f32 v50, v50, %[oz]\n" \
-    "v_mul_f32 v48, %[ix], v48\n v_mul_f32 v49, %[iy], v49\n v_mul_f32 v50, %[iz], v50\n" \
-    "s_waitcnt vmcnt(0)\n" \
-    "v_sub_f32 v52, v52, %[ox]\n v_sub_f32 v53, v53, %[oy]\n v_sub_f32 v54, v54, %[oz]\n" \
-    "v_mul_f32 v52, %[ix], v52\n v_mul_f32 v53, %[iy], v53\n v_mul_f32 v54, %[iz], v54\n" \
-    "v_med3_f32 v56, v48, v52, %[tmin]\n v_med3_f32 v57, %[t], v48, v52\n" \
-    "v_med3_f32 v56, v56, v49, v53\n v_med3_f32 v57, v57, v49, v53\n" \
-    "v_med3_f32 v56, v56, v50, v54\n v_med3_f32 v57, v57, v50, v54\n" \
-    "v_cmp_lt_f32 vcc, v56, v57\n s_nop 1\n" \
-    "v_cndmask_b32 %[code], v51, v55, vcc\n" \
+    "v_sub_f32 " RA0 ", " RA0 ", %[ox]\n v_sub_f32 " RA1 ", " RA1 ", %[oy]\n v_sub_f32 " RA2 ", " RA2 ", %[oz]\n" \
+    "v_mul_f32 " RA0 ", %[ix], " RA0 "\n v_mul_f32 " RA1 ", %[iy], " RA1 "\n v_mul_f32 " RA2 ", %[iz], " RA2 "\n" \
+    PT_RUN_WAIT_B \
+    "v_sub_f32 " RB0 ", " RB0 ", %[ox]\n v_sub_f32 " RB1 ", " RB1 ", %[oy]\n v_sub_f32 " RB2 ", " RB2 ", %[oz]\n" \
+    "v_mul_f32 " RB0 ", %[ix], " RB0 "\n v_mul_f32 " RB1 ", %[iy], " RB1 "\n v_mul_f32 " RB2 ", %[iz], " RB2 "\n" \
+    PT_RUN_CHAINS \
+    "v_cmp_lt_f32 vcc, " RE ", " RF "\n s_nop 1\n" \
+    "v_cndmask_b32 %[code], " RA3 ", " RB3 ", vcc\n" \
     "v_cmp_gt_u32 vcc, %[nspl], %[code]\n" \
     "s_bcnt1_i32_b64 %[cnt], vcc\n s_cmp_ge_i32 %[cnt], %[keep]\n s_cselect_b64 exec, vcc, 0\n"
     if (ALL_IN_LDS) {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUN%=:\n"
-                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
-                     "ds_read_b128 v[48:51], %[code]\n"
+#if PT_LDS_BOTH
+                     "ds_read_b128 " RA ", %[code]\n"
+                     "ds_read_b128 " RB ", %[code] offset:" PT_STR(PT_LDS_N1_OFFSET) "\n"
+                     "s_waitcnt lgkmcnt(1)\n"
+#else
+                     "buffer_load_dwordx4 " RB ", %[code], %[rs1], 0 offen\n"
+                     "ds_read_b128 " RA ", %[code]\n"
                      "s_waitcnt lgkmcnt(0)\n"
+#endif
                      PT_RUN_TEST
                      "s_cbranch_execnz .LPTRUN%=\n"
                      "s_mov_b64 exec, %[save]\n"
                      : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
                      : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
                        [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep)
-                     : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+                     : "vcc", "scc", "memory", PT_RUN_CLOBBERS);
     } else {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUN%=:\n"
                      "v_cmp_gt_u32 vcc, %[lim], %[code]\n"
                      "s_mov_b64 %[cur], exec\n"
-                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
+                     "buffer_load_dwordx4 " RB ", %[code], %[rs1], 0 offen\n"
                      "s_andn2_b64 exec, %[cur], vcc\n"
                      "s_cbranch_execz .LPTNODEEP%=\n"
-                     "buffer_load_dwordx4 v[48:51], %[code], %[rs0], 0 offen\n"
+                     "buffer_load_dwordx4 " RA ", %[code], %[rs0], 0 offen\n"
                      ".LPTNODEEP%=:\n"
                      "s_and_b64 exec, %[cur], vcc\n"
-                     "ds_read_b128 v[48:51], %[code]\n"
+                     "ds_read_b128 " RA ", %[code]\n"
                      "s_mov_b64 exec, %[cur]\n"
                      "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
                      PT_RUN_TEST
@@ -170,7 +211,7 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
                      : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
                        [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
                        [lim] "s"(sc.lds_nodes << 4)
-                     : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+                     : "vcc", "scc", "memory", PT_RUN_CLOBBERS);
     }
 #undef PT_RUN_TEST
     return code;
@@ -259,9 +300,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     // hardware dispatches blockIdx in.
     if ((uint32_t)(uintptr_t)lds_n0 != 0u) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return; }
     const int lds_nodes = sc.lds_nodes;
-    int &ticket = *(int *)&lds_n0[lds_nodes];
+    constexpr bool N1_IN_LDS = PT_LDS_BOTH && ALL_IN_LDS;
+    int &ticket = *(int *)&lds_n0[N1_IN_LDS ? 2 * (PT_LDS_N1_OFFSET / 16) : lds_nodes];
     if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
-    for (int i = threadIdx.x; i < lds_nodes; i += 64 * WAVES_PER_GROUP) lds_n0[i] = sc.n0[i];
+    for (int i = threadIdx.x; i < lds_nodes; i += 64 * WAVES_PER_GROUP) {
+        lds_n0[i] = sc.n0[i];
+        if (N1_IN_LDS) lds_n0[PT_LDS_N1_OFFSET / 16 + i] = sc.n1[i];
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -338,8 +383,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     // SPLIT_ONLY: the caller knows c is a Split code (no Leaf flag to mask)
     auto fetch = [&](int32_t c, float4 &n0, float4 &n1, const bool SPLIT_ONLY = false) {
         const int off = SPLIT_ONLY ? (c << (4 - PT_CODE_SHIFT)) : code_offset(c);
-        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(n1_rsrc, off, 0, 0);
-        n1 = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+        if (N1_IN_LDS) n1 = lds_read((uint32_t)off + PT_LDS_N1_OFFSET);
+        else {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(n1_rsrc, off, 0, 0);
+            n1 = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+        }
         if (ALL_IN_LDS) n0 = lds_read((uint32_t)off);
         else if (off < (lds_nodes << 4)) { n0 = lds_read((uint32_t)off); asm volatile("" : "+v"(n0.x)); }
         else n0 = *(const float4 *)((const char *)sc.n0 + off);
@@ -570,7 +618,7 @@ __global__ __launch_bounds__(64) void primary_hit_kernel(Scene sc, Camera cam, i
     const Ray ray = sample_ray(cam, S, px, py, sample);
     const Hit h = scene_trace<EXT>(sc, ray);
     const int pixel = py * cam.width + px;
-    if (hit_id) hit_id[pixel] = h.prim;
+    if (hit_id) hit_id[pixel] = h.prim >= 0 ? sc.prim_ids[h.prim] : -1;   // device index (rank) -> the caller's id
     if (hit_t) hit_t[pixel] = h.t;
 }
 
@@ -786,9 +834,10 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     if (e != hipSuccess) return e;
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
-    const size_t lds_bytes = ((size_t)sc.lds_nodes + 1) * sizeof(float4);   // + the ticket word
-    const dim3 grid((unsigned)groups), block(64 * WAVES_PER_GROUP);
     const bool in_lds = sc.lds_nodes >= sc.n_nodes;
+    const size_t lds_bytes = PT_LDS_BOTH && in_lds ? 2 * (size_t)PT_LDS_N1_OFFSET + sizeof(float4)
+                                                   : ((size_t)sc.lds_nodes + 1) * sizeof(float4);   // + the ticket word
+    const dim3 grid((unsigned)groups), block(64 * WAVES_PER_GROUP);
     if (!sc.ext) {
         if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
         else hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);

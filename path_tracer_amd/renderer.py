@@ -78,6 +78,15 @@ class ParallelRenderer:
         within the north-star tolerance)."""
         _abi.check(self._ctx, _abi.lib().pt_set_mode(self._ctx, _abi.PT_FAST if fast else _abi.PT_EXACT))
 
+    def set_walk_order(self, view):
+        """pt_set_walk_order: True = PT_WALK_VIEW (default: the child nearer to the camera first), False =
+        PT_WALK_REFERENCE (left child first, bvh.rs:111-118).  Same results either way."""
+        _abi.check(self._ctx, _abi.lib().pt_set_walk_order(self._ctx, _abi.PT_WALK_VIEW if view else _abi.PT_WALK_REFERENCE))
+
+    def walk_order(self):
+        """the order in effect for the uploaded scene (scenes that can tie keep the reference's)"""
+        return _abi.lib().pt_get_walk_order(self._ctx)
+
     def lanes_per_pixel(self, samples, sample_begin, sample_end):
         return _abi.lib().pt_get_lanes_per_pixel(self._ctx, samples, sample_begin, sample_end)
 

@@ -536,3 +536,115 @@ def test_scaled_scenes_bit_exact(renderer, oracle, log2_scale):
     lanes = renderer.lanes_per_pixel(samples, 0, samples * samples)
     chunk = -(-samples * samples // lanes)
     assert same_bits(rad, osc.render(rt.camera.pod, samples, seed=5, chunk=chunk)["radiance"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,s", [("rtow", 160, 90, 4), ("simple", 160, 90, 4), ("reference", 96, 54, 2)])
+def test_walk_orders_agree(renderer, oracle, kind, w, h, s):
+    """pt_set_walk_order: PT_WALK_VIEW (the default every other test runs under: the child nearer to the camera
+    first) and PT_WALK_REFERENCE (left child first, bvh.rs:111-118) return the oracle's hit ids and radiance,
+    bit for bit -- a ray's closest hit does not depend on the order in which its candidates are found."""
+    rt = make_raytracer(kind, w, h, s)
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, s, seed=RENDER_SEED, hit_ids=True)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        for view in (True, False, True):
+            renderer.set_walk_order(view)
+            img, rad, ids = renderer.render(rt, seed=RENDER_SEED, radiance=True, hit_ids=True)
+            assert renderer.walk_order() == int(view)
+            assert np.array_equal(ids, ref["hit_id"])
+            assert same_bits(rad, ref["radiance"])
+            assert np.array_equal(img, osc.resolve(ref["radiance"], s))
+    finally:
+        renderer.set_walk_order(True)
+        renderer.set_lanes_per_pixel(0)
+
+
+@pytest.mark.gpu
+def test_view_order_follows_the_camera(renderer, oracle):
+    """pt_set_camera alone re-threads the node arrays for the new eye (no re-upload of the scene): the same
+    scene seen from the opposite side, then from inside the sphere field, still equals the oracle bit for bit."""
+    import ctypes as C
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    pt.random_scene(scene, 0x5EED5CE7E, pt.RTOW_BOUNDS)
+    first = None
+    renderer.set_lanes_per_pixel(1)
+    try:
+        for eye in ((12.0, 2.0, 3.0), (-12.0, 3.0, -4.0), (0.5, 0.3, 0.5), (0.0, 30.0, 0.1)):
+            cam = pt.Camera.new(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 30.0, 96, 54)
+            rt = pt.Raytracer.new(cam, scene, 3)
+            if first is None:
+                first = rt
+                renderer.bind(rt)
+            else:                                   # camera only: the scene stays as uploaded for `first`
+                pt._abi.check(renderer._ctx, pt.lib().pt_set_camera(renderer._ctx, C.byref(cam.pod)))
+                rt.packed, rt.nodes = first.packed, first.nodes
+                renderer._raytracer = rt
+            osc = oracle.OracleScene(rt.packed)
+            ref = osc.render(cam.pod, 3, seed=3, hit_ids=True)
+            img, rad, ids = renderer.render(rt, seed=3, radiance=True, hit_ids=True)
+            assert renderer.walk_order() == 1
+            assert np.array_equal(ids, ref["hit_id"])
+            assert same_bits(rad, ref["radiance"])
+    finally:
+        renderer._raytracer = None
+        renderer.set_lanes_per_pixel(0)
+
+
+@pytest.mark.gpu
+def test_ties_go_to_the_reference_walks_first_candidate(renderer, oracle):
+    """Two spheres with the same centre and radius return the same t for every ray; the reference keeps the one
+    its walk meets first (strict '<', sphere.rs:57).  Under PT_WALK_VIEW the walk may meet them the other way
+    round: the lower rank in the reference's order wins the tie (pt_device.hpp closer), from either side."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, -100.5, -1.0), 100.0, pt.Lambertian.new_solid((0.8, 0.8, 0.0))))
+    scene.add(pt.Sphere.new((0.0, 0.0, -1.0), 0.5, pt.Lambertian.new_solid((0.9, 0.1, 0.1))))
+    scene.add(pt.Sphere.new((1.0, 0.0, -1.0), 0.5, pt.Metal.new((0.8, 0.6, 0.2), 0.0)))
+    scene.add(pt.Sphere.new((0.0, 0.0, -1.0), 0.5, pt.Dielectric.new(1.5)))
+    scene.add(pt.Sphere.new((-1.0, 0.0, -1.0), 0.5, pt.Dielectric.new(1.5)))
+    scene.add(pt.Sphere.new((1.0, 0.0, -1.0), 0.5, pt.Lambertian.new_solid((0.1, 0.1, 0.9))))
+    try:
+        for eye in ((0.0, 0.5, 2.0), (0.0, 0.5, -4.0), (5.0, 0.2, -1.0), (-5.0, 0.2, -1.0)):
+            cam = pt.Camera.new(eye, (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 60.0, 64, 36)
+            rt = pt.Raytracer.new(cam, scene, 3)
+            osc = oracle.OracleScene(rt.packed)
+            ref = osc.render(cam.pod, 3, seed=9, hit_ids=True)
+            lanes = None
+            for view in (True, False):
+                renderer.set_walk_order(view)
+                img, rad, ids = renderer.render(rt, seed=9, radiance=True, hit_ids=True)
+                assert renderer.walk_order() == int(view)
+                assert np.array_equal(ids, ref["hit_id"])
+                lanes = renderer.lanes_per_pixel(3, 0, 9)
+                assert same_bits(rad, osc.render(cam.pod, 3, seed=9, chunk=-(-9 // lanes))["radiance"])
+    finally:
+        renderer.set_walk_order(True)
+
+
+@pytest.mark.gpu
+def test_boxes_that_do_not_contain_their_spheres_keep_the_reference_order(renderer, oracle):
+    """A sphere of negative radius (the hollow-glass idiom) gets a box with min and max swapped
+    (Sphere::bounding_box is centre -+ radius as written, sphere.rs:71-76), and the boxes above it no longer
+    contain it: a box test can then hide a closer hit behind a farther one found earlier, so the result depends
+    on the order of the walk.  Such a tree is walked in the reference's order whatever pt_set_walk_order says."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, -100.5, -1.0), 100.0, pt.Lambertian.new_solid((0.8, 0.8, 0.0))))
+    scene.add(pt.Sphere.new((0.0, 0.0, -1.0), 0.5, pt.Lambertian.new_solid((0.1, 0.2, 0.5))))
+    scene.add(pt.Sphere.new((-1.0, 0.0, -1.0), 0.5, pt.Dielectric.new(1.5)))
+    scene.add(pt.Sphere.new((2.6, 0.0, -1.0), -0.45, pt.Dielectric.new(1.5)))     # on its own: nothing else covers it
+    scene.add(pt.Sphere.new((1.0, 0.0, -1.0), 0.5, pt.Metal.new((0.8, 0.6, 0.2), 0.0)))
+    for eye in ((3.0, 2.0, 2.0), (-3.0, 0.5, -4.0)):
+        cam = pt.Camera.new(eye, (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 40.0, 64, 36)
+        rt = pt.Raytracer.new(cam, scene, 4)
+        osc = oracle.OracleScene(rt.packed)
+        ref = osc.render(cam.pod, 4, seed=2, hit_ids=True)
+        renderer.set_walk_order(True)
+        img, rad, ids = renderer.render(rt, seed=2, radiance=True, hit_ids=True)
+        assert renderer.walk_order() == 0
+        assert np.array_equal(ids, ref["hit_id"])
+        lanes = renderer.lanes_per_pixel(4, 0, 16)
+        assert same_bits(rad, osc.render(cam.pod, 4, seed=2, chunk=-(-16 // lanes))["radiance"])
