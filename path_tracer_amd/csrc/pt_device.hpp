@@ -470,7 +470,7 @@ PTD LeafCandidate leaf_candidate(const float4 n0, const f3 o, const f3 d, const 
     }
     LeafCandidate k;
     k.sure = (bool)((int)first | ((int)need2 & (int)(sol2 < closest) & (int)(sol2 > T_MIN)));
-#ifndef PT_NO_TIE   // (PT_NO_TIE: measurement builds only -- ties go to the walk's first candidate)
+#ifndef PT_NO_TIE   // (PT_NO_TIE: the FAST build and measurement builds -- ties go to the walk's first candidate)
     // a first root that ties is followed by a second one >= it, which can only tie as well: either way the lane
     // offers `closest` itself (h.t stays as it is) and the rank decides
     k.tie = (bool)((int)need2 & ((int)(sol1 == closest) | (int)(sol2 == closest)));

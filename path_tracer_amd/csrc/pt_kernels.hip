@@ -101,10 +101,9 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #endif
 constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
 // PT_LDS_BOTH (measurement; off): a tree that fits the LDS prefix keeps BOTH halves of its nodes in LDS (n1[] at
-// byte offset PT_LDS_N1_OFFSET of the group's allocation), so that a node visit costs no L1 access at all.  Slower:
-// 32 KiB per group needs groups of 8 waves to keep 8 waves per SIMD, and at that group size two LDS reads per
-// node take 545 ms against 497 ms for one LDS read + one L1 read (441 ms-equivalent build; groups of 4: 718 ms,
-// of 16: 613 ms): LDS bandwidth, not the L1, is the scarcer of the two.
+// byte offset PT_LDS_N1_OFFSET of the group's allocation), so that a node visit costs no L1 access at all.  32 KiB
+// per group needs groups of 8 waves to keep 8 waves per SIMD: 561 ms against 583 ms for one LDS + one L1 read at
+// that group size -- and 521 ms for groups of 4 (both halves in LDS with groups of 4: 734 ms, of 16: 631 ms).
 #ifndef PT_LDS_BOTH
 #define PT_LDS_BOTH 0
 #endif
@@ -137,7 +136,11 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
 // Scratch registers of the run: A = n0 (v48-51), B = n1 (v52-55), E / F = the tmin / tmax chains (v56, v57).
 // Each pair (n0.k, n1.k) shares a VGPR bank (register number mod 4); a layout in which no instruction reads two
 // scratch registers of one bank (A = v46-49, B = v52-55, E = v51, F = v57, chains y, x, z) measured the same
-// (520.6 vs 521.0 ms): operand banks do not limit this loop.
+// (520.6 vs 521.0 ms): operand banks do not limit this loop.  What an instruction MORE in this loop costs, each
+// measured by adding one (522 ms frame): a vector-memory load of any width +110 ms (the same 16 bytes as a 12- and
+// a 4-byte load: 632 ms) -- the CU's address unit takes every lane's address, whatever the width; an LDS read of
+// 4, 8 or 16 bytes: nothing (522-526 ms).  Taking the one vector-memory load OUT (PT_LDS_BOTH) gains only 22 ms at
+// equal group size, less than the 62 ms the larger groups it needs cost.
 #define RA0 "v48"
 #define RA1 "v49"
 #define RA2 "v50"

@@ -12,6 +12,8 @@
 // 100 spp, where one path that goes another way moves a pixel by more than 1/255; converged RMSE < 1e-3:
 // tests/test_gpu_fast.py).  The default mode, every other kernel, the primary-hit AOV (bit-exact hit ids)
 // and the extension's scenes always use the EXACT build.  Only ptk_fast::launch_path comes out of this file.
+// Exact ties in t go to the candidate the walk meets first (no rank rule: PT_NO_TIE), whatever the walk order.
 #pragma clang fp contract(fast)
 #define PT_FAST_MODE 1
+#define PT_NO_TIE 1
 #include "pt_kernels.hip"
