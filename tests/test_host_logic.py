@@ -244,3 +244,74 @@ def test_group_create_argument_errors():
     assert lib.pt_group_create(two, 2, C.byref(out)) == -1          # a device listed twice
     assert b"twice" in lib.pt_group_last_error(None)
     assert lib.pt_group_size(None) == 0 and not lib.pt_group_context(None, 0)
+
+
+def _c_structs(header):
+    """{name: [(field, rust type)]} for every `typedef struct { ... } name;` of the header"""
+    ctype = {"float": "f32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "char": "c_char"}
+    out = {}
+    for body, name in re.findall(r"typedef struct \{(.*?)\}\s*(pt_[a-z_]+);", header, re.S):
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in filter(None, (d.strip() for d in body.split(";"))):
+            m = re.match(r"(const\s+)?(\w+)\s+(.*)", decl, re.S)
+            const, base, rest = m.group(1), m.group(2), m.group(3)
+            for item in (x.strip() for x in rest.split(",")):
+                ptr = item.startswith("*")
+                ident, dim = re.match(r"\*?\s*(\w+)(?:\[(\d+)\])?", item).groups()
+                rust = {"uint8_t": "u8"}.get(base, ctype.get(base))
+                assert rust, decl
+                if ptr:
+                    rust = ("*const " if const else "*mut ") + rust
+                if dim:
+                    rust = "[%s; %s]" % (rust, dim)
+                fields.append((ident, rust))
+        out[name] = fields
+    return out
+
+
+def _rust_structs(source):
+    out = {}
+    for name, body in re.findall(r"#\[repr\(C\)\][^\n]*\npub struct (pt_\w+)\s*\{(.*?)\}", source, re.S):
+        out[name] = [(f, " ".join(t.split())) for f, t in re.findall(r"pub (\w+):\s*([^,}]+?)\s*(?:,|$)", body.strip(), re.S)]
+    return out
+
+
+def _params(arglist):
+    depth, n, seen = 0, 0, False
+    for ch in arglist:
+        if ch in "(<[":
+            depth += 1
+        elif ch in ")>]":
+            depth -= 1
+        elif ch == "," and depth == 0:
+            n += 1
+        if not ch.isspace():
+            seen = True
+    return n + 1 if seen and arglist.strip() != "void" else 0
+
+
+def test_rust_binding_matches_header():
+    """integration/rust/src/gpu.rs (uncompiled: no rustc here) against include/pt_amd.h: every struct with the
+    same fields, in order, with the corresponding Rust types; every export declared, with the same number of
+    parameters; the constants of the header's enums with the same values."""
+    header = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
+    rust = open(os.path.join(ROOT, "integration", "rust", "src", "gpu.rs")).read()
+    c_structs, r_structs = _c_structs(header), _rust_structs(rust)
+    assert set(c_structs) == set(r_structs), set(c_structs) ^ set(r_structs)
+    for name, fields in c_structs.items():
+        assert fields == r_structs[name], (name, fields, r_structs[name])
+    nocomment = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    c_fns = {n: _params(a) for n, a in re.findall(r"\b(pt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", nocomment, re.S)}
+    extern = rust[rust.index('extern "C" {'):]
+    extern = re.sub(r"//[^\n]*", "", extern[:extern.index("\n}\n")])
+    r_fns = {n: _params(a) for n, a in re.findall(r"pub fn (pt_\w+)\((.*?)\)\s*(?:->[^;]+)?;", extern, re.S)}
+    assert set(c_fns) == set(_abi.SIGNATURES)
+    assert set(r_fns) == set(c_fns), set(r_fns) ^ set(c_fns)
+    assert r_fns == c_fns, {n: (c_fns[n], r_fns[n]) for n in c_fns if c_fns[n] != r_fns[n]}
+    c_consts = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}", nocomment, re.S) + re.findall(r"typedef enum\s*\{(.*?)\}", nocomment, re.S):
+        for n, v in re.findall(r"(PT_[A-Z_]+)\s*=\s*(-?\d+)", body):
+            c_consts[n] = int(v)
+    r_consts = {n: int(v) for n, v in re.findall(r"pub const (PT_[A-Z_]+): \w+ = (-?\d+);", rust)}
+    assert r_consts == c_consts, set(r_consts.items()) ^ set(c_consts.items())
