@@ -33,6 +33,7 @@ struct Scene {
     // extension scenes only (pt_upload_scene_ext)
     const float4 *xforms;    // per transform: (offset.xyz, sin theta), (cos theta, -, -, -)
     int32_t ext;             // 1: rendered by the extension's kernel instantiation
+    int32_t lds_xforms;      // the path kernel stages this many transforms (all of them, or 0) in LDS behind the nodes
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;
@@ -496,9 +497,22 @@ PTD void leaf_step(const float4 n0, const float4 n1, const f3 o, const f3 d, con
 // Leaf of a rect:  n0 = (a0, a1, b0, b1)   n1 = (k, bits(flags), bits(prim), bits(next code))
 // flags: bit 0 = rect, bits 1-2 = axis, bit 3 = flip, bits 4.. = transform index + 1; a sphere's Leaf has flags 0.
 struct Xform { f3 off; float s, c; };
-PTD Xform load_xform(const Scene &sc, int idx)
+// xf_lds: LDS byte address of the staged transform table (path kernel), or XF_GLOBAL: read sc.xforms.  A
+// vector-memory load costs the CU's address unit as much as a node visit does; an LDS read
+// is free next to it, and a rect test of an instance needs its transform every time.
+constexpr uint32_t XF_GLOBAL = 0xffffffffu;
+PTD float4 lds_f4(uint32_t addr)
 {
-    const float4 a = sc.xforms[2 * idx], b = sc.xforms[2 * idx + 1];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f lds_v4f;
+    const v4f t = *(lds_v4f *)(uintptr_t)addr;
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+PTD Xform load_xform(const Scene &sc, int idx, const uint32_t xf_lds)
+{
+    float4 a, b;
+    if (xf_lds != XF_GLOBAL) { a = lds_f4(xf_lds + 32u * (uint32_t)idx); b = lds_f4(xf_lds + 32u * (uint32_t)idx + 16u); }
+    else { a = sc.xforms[2 * idx]; b = sc.xforms[2 * idx + 1]; }
     Xform x; x.off = mk(a.x, a.y, a.z); x.s = a.w; x.c = b.x;
     return x;
 }
@@ -506,22 +520,22 @@ PTD f3 rot_to_object(const Xform &x, f3 p) { return mk(x.c * p.x - x.s * p.z, p.
 PTD f3 rot_to_world(const Xform &x, f3 p) { return mk(x.c * p.x + x.s * p.z, p.y, x.c * p.z - x.s * p.x); }
 PTD float pick(f3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 // the ray in the rect's object space (un-normalised: t is the same in both spaces)
-PTD void rect_object_ray(const Scene &sc, int flags, f3 &o, f3 &d)
+PTD void rect_object_ray(const Scene &sc, int flags, f3 &o, f3 &d, const uint32_t xf_lds)
 {
     const int xf = (flags >> 4) - 1;
     if (xf >= 0) {
-        const Xform x = load_xform(sc, xf);
+        const Xform x = load_xform(sc, xf, xf_lds);
         o = rot_to_object(x, o - x.off);
         d = rot_to_object(x, d);
     }
 }
 // Traceable::trace of a rect: t = (k - o[axis]) / d[axis], accepted iff t < max_t && t > min_t (the
 // comparison of sphere.rs:57) and the point lies in [a0, a1] x [b0, b1]; a NaN fails every test
-PTD void rect_step(const Scene &sc, const float4 n0, const float4 n1, f3 o, f3 d, Hit &h)
+PTD void rect_step(const Scene &sc, const float4 n0, const float4 n1, f3 o, f3 d, Hit &h, const uint32_t xf_lds = XF_GLOBAL)
 {
     const int flags = __float_as_int(n1.y);
     const int axis = (flags >> 1) & 3;
-    rect_object_ray(sc, flags, o, d);
+    rect_object_ray(sc, flags, o, d, xf_lds);
     const int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
     const float t = (n1.x - pick(o, axis)) / pick(d, axis);
     if (!(t < h.t && t > T_MIN)) return;
@@ -634,7 +648,8 @@ PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f
 }
 // Extension: the record of a sphere or a rect, the light's emitted term, then scatter.
 //   prims[2 i] of a rect = (bits(flags), -, -, bits(kind | 1 << 30)); flags as in its Leaf (rect_step)
-PTD bool scatter_ext(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out, f3 &emitted, bool &light)
+PTD bool scatter_ext(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out, f3 &emitted, bool &light,
+                     const uint32_t xf_lds = XF_GLOBAL)
 {
     const float4 sp = sc.prims[2 * h.prim];
     const float4 ma = sc.prims[2 * h.prim + 1];
@@ -645,12 +660,12 @@ PTD bool scatter_ext(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rn
         const int flags = __float_as_int(sp.x);
         const int axis = (flags >> 1) & 3, xf = (flags >> 4) - 1;
         f3 o = ray.o, d = ray.d;
-        rect_object_ray(sc, flags, o, d);
+        rect_object_ray(sc, flags, o, d, xf_lds);
         p = o + d * h.t;
         const float one = (flags & 8) ? -1.0f : 1.0f;
         n = mk(axis == 0 ? one : 0.0f, axis == 1 ? one : 0.0f, axis == 2 ? one : 0.0f);
         if (xf >= 0) {
-            const Xform x = load_xform(sc, xf);
+            const Xform x = load_xform(sc, xf, xf_lds);
             p = rot_to_world(x, p) + x.off;
             n = rot_to_world(x, n);
         }

@@ -81,7 +81,7 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #define PT_FAST_DIV 1
 #endif
 #ifndef PT_W_SPLIT
-#define PT_W_SPLIT 4
+#define PT_W_SPLIT 3
 #endif
 #ifndef PT_W_LEAF
 #define PT_W_LEAF 5
@@ -310,6 +310,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         lds_n0[i] = sc.n0[i];
         if (N1_IN_LDS) lds_n0[PT_LDS_N1_OFFSET / 16 + i] = sc.n1[i];
     }
+    // extension scenes: the instance transforms (two float4 each) behind the ticket word
+    const int xf_slot = (N1_IN_LDS ? 2 * (PT_LDS_N1_OFFSET / 16) : lds_nodes) + 1;
+    const uint32_t xf_lds = EXT && sc.lds_xforms > 0 ? (uint32_t)xf_slot * 16u : XF_GLOBAL;
+    if (EXT)
+        for (int i = threadIdx.x; i < 2 * sc.lds_xforms; i += 64 * WAVES_PER_GROUP) lds_n0[xf_slot + i] = sc.xforms[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                         PT_STAT(1, lanes(true));
                         float4 n0, n1;
                         fetch(code, n0, n1);
-                        if (EXT && (__float_as_int(n1.y) & 1)) rect_step(sc, n0, n1, ray.o, ray.d, h);
+                        if (EXT && (__float_as_int(n1.y) & 1)) rect_step(sc, n0, n1, ray.o, ray.d, h, xf_lds);
                         else leaf_step(n0, n1, ray.o, ray.d, a, ra, PT_FAST_DIV && all_regular, h);
                         code = __float_as_int(n1.w);
                         const bool at = code < 0;
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 bool scattered;
                 if (EXT) {
                     f3 emitted; bool light;
-                    scattered = scatter_ext(sc, ray, h, rng, am, nr, emitted, light);
+                    scattered = scatter_ext(sc, ray, h, rng, am, nr, emitted, light, xf_lds);
                     if (light) rad = rad + emitted * att;                        // Material::emitted, before scatter's verdict
                 } else {
                     scattered = scatter(sc, ray, h, rng, am, nr);
@@ -838,8 +843,9 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
     const bool in_lds = sc.lds_nodes >= sc.n_nodes;
-    const size_t lds_bytes = PT_LDS_BOTH && in_lds ? 2 * (size_t)PT_LDS_N1_OFFSET + sizeof(float4)
-                                                   : ((size_t)sc.lds_nodes + 1) * sizeof(float4);   // + the ticket word
+    const size_t lds_bytes = (PT_LDS_BOTH && in_lds ? 2 * (size_t)PT_LDS_N1_OFFSET + sizeof(float4)
+                                                    : ((size_t)sc.lds_nodes + 1) * sizeof(float4))   // + the ticket word
+                             + (sc.ext ? 2 * (size_t)sc.lds_xforms * sizeof(float4) : 0);
     const dim3 grid((unsigned)groups), block(64 * WAVES_PER_GROUP);
     if (!sc.ext) {
         if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);

@@ -23,6 +23,7 @@ last = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 r = pt.ParallelRenderer.new(0)
 bad = []
 paths = 0
+view_order = 0        # cases the library walked nearer-child-first (PT_WALK_VIEW in effect)
 t0 = time.time()
 for k in range(first, last):
     rt, samples = _fuzz_case(k)
@@ -31,6 +32,7 @@ for k in range(first, last):
     r.set_lanes_per_pixel(1)
     img, rad, ids = r.render(rt, seed=k, radiance=True, hit_ids=True)
     r.set_lanes_per_pixel(0)
+    view_order += r.walk_order()
     ok = np.array_equal(ids, ref["hit_id"]) and np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
     r.bind(rt)
     lanes = r.lanes_per_pixel(samples, 0, samples * samples)
@@ -44,7 +46,8 @@ for k in range(first, last):
     osc.close()
     if k % 50 == 0:
         print("case %d, %d mismatching so far, %.0f s" % (k, len(bad), time.time() - t0), flush=True)
-out = {"cases": last - first, "first": first, "last": last, "paths": int(paths), "mismatching_cases": bad}
+out = {"cases": last - first, "first": first, "last": last, "paths": int(paths), "mismatching_cases": bad,
+       "cases_walked_in_view_order": int(view_order)}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_campaign.json"), "w"))

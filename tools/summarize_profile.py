@@ -9,17 +9,18 @@ import shutil
 import sys
 
 src, dst, note = sys.argv[1], sys.argv[2], sys.argv[3]
+kernel = sys.argv[4] if len(sys.argv) > 4 else "path_kernel"   # substring of the kernel's name (path_kernel_fast: the PT_FAST build)
 stats = glob.glob(src + "/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, dst + "_kernel_stats.csv")
 agg = collections.defaultdict(list)
 for f in glob.glob(src + "/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "path_kernel" in r["Kernel_Name"]:
+        if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 avg_ns = None
 for r in csv.DictReader(open(stats)):
-    if "path_kernel" in r["Name"]:
+    if kernel in r["Name"]:
         avg_ns = float(r["AverageNs"])
 d = {}
 if "SQ_THREAD_CYCLES_VALU" in m:
