@@ -212,24 +212,29 @@ int thread_nodes(pt_context *c)
         second[i] = swap ? l : r;
     }
     // walk order (depth-first, first child before second) and every node's successor
-    stack.push_back(0);
-    while (!stack.empty()) {
-        const int32_t i = stack.back();
-        stack.pop_back();
-        walk.push_back(i);
-        if (nodes[i].prim < 0) {
-            succ[first[i]] = second[i];
-            succ[second[i]] = succ[i];
-            stack.push_back(second[i]);
-            stack.push_back(first[i]);
+    try {
+        stack.push_back(0);
+        while (!stack.empty()) {
+            const int32_t i = stack.back();
+            stack.pop_back();
+            if ((int32_t)walk.size() >= n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
+            walk.push_back(i);                          // within the reservation
+            if (nodes[i].prim < 0) {
+                succ[first[i]] = second[i];
+                succ[second[i]] = succ[i];
+                stack.push_back(second[i]);             // the stack is as deep as the tree: may grow
+                stack.push_back(first[i]);
+            }
         }
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
     }
     if ((int32_t)walk.size() != n_nodes) return fail(c, PT_ERR_INVALID, "BVH is not a single tree");
     order.push_back(0);
-    for (size_t q = 0; q < order.size() && order.size() < (size_t)n_nodes; q++) {
+    for (size_t q = 0; q < order.size() && order.size() + 2 <= (size_t)n_nodes; q++) {
         const int32_t i = order[q];
         if (nodes[i].prim < 0) {
-            order.push_back(first[i]);
+            order.push_back(first[i]);                  // within the reservation
             order.push_back(second[i]);
         }
     }
