@@ -505,7 +505,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
                 PT_TIME(0);
             } else if (vL >= vZ) {
                 // LEAF run: one Sphere::trace per iteration for the lanes standing on a Leaf
-                const int keepL = (cL * PT_LEAF_KEEP + 7) >> 3;
+                // (extension scenes: small trees, dear rect tests -- a run goes on while half of its starters remain: -3 %)
+                const int keepL = (cL * (EXT ? 4 : PT_LEAF_KEEP) + 7) >> 3;
                 if (code < 0) {
                     for (;;) {
                         PT_STAT(1, lanes(true));
