@@ -283,40 +283,19 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
 }
 #endif
 
-// EXT: the instantiation for scenes uploaded with pt_upload_scene_ext (rects, instances, lights, integrator
-// options; DESIGN.md section 10).  The reference's scenes always run EXT = false, whose code is unchanged.
-template <bool ALL_IN_LDS, bool EXT = false>
-__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
-                                                                    float *radiance)
+// One (piece, tile) item, rendered by one wave.  The kernels below hand the items out: path_kernel one per wave
+// of a workgroup that then ends, path_kernel_persistent in a loop.
+template <bool ALL_IN_LDS, bool EXT>
+__device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, const RenderParams &rp, const SchedParams &sched,
+                                            float *radiance, const int item, const uint32_t xf_lds)
 {
-    // dynamic LDS: n0[0 .. lds_nodes) then the group's ticket.  There is no static __shared__
-    // in this kernel, so the array starts at LDS address 0 and 16 * slot IS the LDS address of
-    // a node's n0 entry: no base add per node visit (checked below: error flag 2).
     extern __shared__ float4 lds_n0[];
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const v4f lds_f4;
     auto lds_read = [](uint32_t addr) -> float4 { const v4f t = *(lds_f4 *)(uintptr_t)addr; return make_float4(t.x, t.y, t.z, t.w); };
-    // One ticket per workgroup, drawn while the nodes are staged: the group's waves take the
-    // (piece, tile) items 4*ticket .. 4*ticket+3.  Tickets follow the order in which groups
-    // START, so the item a wave may have to wait for (same tile, previous piece: a lower
-    // item) belongs to a group that is already running or done -- whatever order the
-    // hardware dispatches blockIdx in.
-    if ((uint32_t)(uintptr_t)lds_n0 != 0u) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return; }
     const int lds_nodes = sc.lds_nodes;
     constexpr bool N1_IN_LDS = PT_LDS_BOTH && ALL_IN_LDS;
-    int &ticket = *(int *)&lds_n0[N1_IN_LDS ? 2 * (PT_LDS_N1_OFFSET / 16) : lds_nodes];
-    if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
-    for (int i = threadIdx.x; i < lds_nodes; i += 64 * WAVES_PER_GROUP) {
-        lds_n0[i] = sc.n0[i];
-        if (N1_IN_LDS) lds_n0[PT_LDS_N1_OFFSET / 16 + i] = sc.n1[i];
-    }
-    // extension scenes: the instance transforms (two float4 each) behind the ticket word
-    const int xf_slot = (N1_IN_LDS ? 2 * (PT_LDS_N1_OFFSET / 16) : lds_nodes) + 1;
-    const uint32_t xf_lds = EXT && sc.lds_xforms > 0 ? (uint32_t)xf_slot * 16u : XF_GLOBAL;
-    if (EXT)
-        for (int i = threadIdx.x; i < 2 * sc.lds_xforms; i += 64 * WAVES_PER_GROUP) lds_n0[xf_slot + i] = sc.xforms[i];
-    __syncthreads();
-
+    (void)xf_lds;
     const int lane = threadIdx.x & 63;
     const int L = rp.lanes;
     const int P = 64 / L;
@@ -326,7 +305,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     const int tiles_x = (cam.width + tw - 1) / tw;
     const int S = rp.S;
     const int n_nodes = sc.n_nodes << PT_CODE_SHIFT;   // in code units: the code that ends a walk
-    const int n_items = sched.n_tiles * sched.n_pieces;
     const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, sc.n_nodes * 16, 0x00020000);
 
   // A wave renders ONE item: a tile's pixels x a contiguous piece of the sample indices.
@@ -334,8 +312,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
   // whole tile x all samples per wave left the chip at 4.75 of 8 waves per SIMD on average:
   // profiles/r01/v2); a loop over items inside the wave cost 4-20 % in code quality.
   {
-    const int item = __builtin_amdgcn_readfirstlane(ticket) * WAVES_PER_GROUP + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (item >= n_items) return;
     const int piece = item / sched.n_tiles, tile = item - piece * sched.n_tiles;
     const int ps0 = rp.s0 + piece * sched.piece_len;
     const int ps1 = ps0 + sched.piece_len < rp.s1 ? ps0 + sched.piece_len : rp.s1;
@@ -613,6 +589,92 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
   }
 }
 
+// EXT: the instantiation for scenes uploaded with pt_upload_scene_ext (rects, instances, lights, integrator
+// options; DESIGN.md section 10).  The reference's scenes always run EXT = false, whose code is unchanged.
+// Stages the group's LDS copy of the nodes (and transforms); returns the LDS address of the transform table.
+template <bool ALL_IN_LDS, bool EXT>
+__device__ __forceinline__ bool stage_group(const Scene &sc, const SchedParams &sched, uint32_t &xf_lds, int &ticket_slot)
+{
+    // dynamic LDS: n0[0 .. lds_nodes) then the group's ticket.  There is no static __shared__
+    // in this kernel, so the array starts at LDS address 0 and 16 * slot IS the LDS address of
+    // a node's n0 entry: no base add per node visit (checked here: error flag 2).
+    extern __shared__ float4 lds_n0[];
+    if ((uint32_t)(uintptr_t)lds_n0 != 0u) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return false; }
+    const int lds_nodes = sc.lds_nodes;
+    constexpr bool N1_IN_LDS = PT_LDS_BOTH && ALL_IN_LDS;
+    ticket_slot = N1_IN_LDS ? 2 * (PT_LDS_N1_OFFSET / 16) : lds_nodes;
+    for (int i = threadIdx.x; i < lds_nodes; i += blockDim.x) {
+        lds_n0[i] = sc.n0[i];
+        if (N1_IN_LDS) lds_n0[PT_LDS_N1_OFFSET / 16 + i] = sc.n1[i];
+    }
+    // extension scenes: the instance transforms (two float4 each) behind the ticket word
+    const int xf_slot = ticket_slot + 1;
+    xf_lds = EXT && sc.lds_xforms > 0 ? (uint32_t)xf_slot * 16u : XF_GLOBAL;
+    if (EXT)
+        for (int i = threadIdx.x; i < 2 * sc.lds_xforms; i += blockDim.x) lds_n0[xf_slot + i] = sc.xforms[i];
+    return true;
+}
+
+template <bool ALL_IN_LDS, bool EXT = false>
+__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
+                                                                    float *radiance)
+{
+    // One ticket per workgroup, drawn while the nodes are staged: the group's waves take the
+    // (piece, tile) items 4*ticket .. 4*ticket+3.  Tickets follow the order in which groups
+    // START, so the item a wave may have to wait for (same tile, previous piece: a lower
+    // item) belongs to a group that is already running or done -- whatever order the
+    // hardware dispatches blockIdx in.
+    extern __shared__ float4 lds_n0[];
+    uint32_t xf_lds; int ticket_slot;
+    if (!stage_group<ALL_IN_LDS, EXT>(sc, sched, xf_lds, ticket_slot)) return;
+    int &ticket = *(int *)&lds_n0[ticket_slot];
+    if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
+    __syncthreads();
+    const int n_items = sched.n_tiles * sched.n_pieces;
+    const int item = __builtin_amdgcn_readfirstlane(ticket) * WAVES_PER_GROUP + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (item >= n_items) return;
+    render_item<ALL_IN_LDS, EXT>(sc, cam, rp, sched, radiance, item, xf_lds);
+}
+
+#ifdef PT_PERSISTENT
+// Persistent variant (measurement): as many workgroups as the chip holds, each wave drawing items until none are
+// left.  The item's code is a real function call, so that nothing of its register allocation leaks into the loop.
+struct PathArgs { Scene sc; Camera cam; RenderParams rp; SchedParams sched; float *radiance; };
+// The arguments travel as the address of the kernel's own argument block (constant address space, so the
+// function reads them with scalar loads): __builtin_amdgcn_kernarg_segment_ptr() is NULL inside a callee -- the
+// kernel has to hand the pointer over.  Function arguments arrive in vector registers: made uniform again first.
+typedef __attribute__((address_space(4))) const PathArgs *PathArgsPtr;
+template <bool ALL_IN_LDS, bool EXT>
+__device__ __attribute__((noinline)) void render_item_call(const uint32_t args_lo, const uint32_t args_hi, const int item_v, const uint32_t xf_lds_v)
+{
+    const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)args_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)args_lo);
+    const PathArgsPtr a = (PathArgsPtr)addr;
+    const int item = __builtin_amdgcn_readfirstlane(item_v);
+    const uint32_t xf_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)xf_lds_v);
+    const Scene sc = a->sc;
+    const Camera cam = a->cam;
+    const RenderParams rp = a->rp;
+    const SchedParams sched = a->sched;
+    render_item<ALL_IN_LDS, EXT>(sc, cam, rp, sched, a->radiance, item, xf_lds);
+}
+template <bool ALL_IN_LDS, bool EXT = false>
+__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel_persistent(PathArgs a)
+{
+    uint32_t xf_lds; int ticket_slot;
+    if (!stage_group<ALL_IN_LDS, EXT>(a.sc, a.sched, xf_lds, ticket_slot)) return;
+    __syncthreads();
+    const int n_items = a.sched.n_tiles * a.sched.n_pieces;
+    const uint64_t args = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // PathArgs is the kernel's only argument: offset 0
+    for (;;) {
+        int item = 0;
+        if ((threadIdx.x & 63) == 0) item = atomicAdd(&a.sched.ctrl[0], 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        render_item_call<ALL_IN_LDS, EXT>((uint32_t)args, (uint32_t)(args >> 32), item, xf_lds);
+    }
+}
+#endif
+
 #ifndef PT_FAST_MODE   // everything from here to the launchers is built once, in the EXACT translation unit
 // K1: primitive id (and t) hit by the primary ray of one sample index.
 template <bool EXT>
@@ -848,6 +910,23 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
                                                     : ((size_t)sc.lds_nodes + 1) * sizeof(float4))   // + the ticket word
                              + (sc.ext ? 2 * (size_t)sc.lds_xforms * sizeof(float4) : 0);
     const dim3 grid((unsigned)groups), block(64 * WAVES_PER_GROUP);
+#ifdef PT_PERSISTENT
+    if (!sc.ext) {
+        // as many workgroups as the chip holds at once; each wave draws items until none are left
+        const PathArgs args{sc, cam, rp, sp, d_radiance};
+        int per_cu = 0, cus = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (in_lds) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel_persistent<true, false>, 64 * WAVES_PER_GROUP, lds_bytes);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel_persistent<false, false>, 64 * WAVES_PER_GROUP, lds_bytes);
+        long long resident = (long long)per_cu * cus;
+        if (resident < 1) resident = 1;
+        const dim3 pgrid((unsigned)(groups < resident ? groups : resident));
+        if (in_lds) hipLaunchKernelGGL((path_kernel_persistent<true, false>), pgrid, block, lds_bytes, stream, args);
+        else hipLaunchKernelGGL((path_kernel_persistent<false, false>), pgrid, block, lds_bytes, stream, args);
+        return hipGetLastError();
+    }
+#endif
     if (!sc.ext) {
         if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
         else hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
