@@ -67,6 +67,13 @@ int ensure_frame(pt_context *c)
 int check_kernel_error(pt_context *c)
 {
     if (!c->last_sched) return PT_OK;
+#ifdef PT_PHASES
+    {   // measurement build: cycle sums the persistent kernel left in the control words
+        unsigned long long w[16] = {0};
+        if (hipMemcpy(w, c->last_sched, sizeof w, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "PT_PHASES items %d waves %llu draw %llu item %llu wait %llu\n", (int)(w[0] & 0xffffffffu), w[10], w[8], w[9], w[11]);
+    }
+#endif
     int32_t ctrl[2] = {0, 0};
     PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
     if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
@@ -950,6 +957,13 @@ float pt_last_path_kernel_ms(pt_context *c)
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0f;
     // the launch is complete: its error word can be read (see pt_render)
+#ifdef PT_PHASES
+    {   // measurement build: cycle sums the persistent kernel left in the control words
+        unsigned long long w[16] = {0};
+        if (c->last_sched && hipMemcpy(w, c->last_sched, sizeof w, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "PT_PHASES ms %.3f items %d waves %llu draw %llu item %llu wait %llu\n", ms, (int)(w[0] & 0xffffffffu), w[10], w[8], w[9], w[11]);
+    }
+#endif
     int32_t ctrl[2] = {0, 0};
     if (c->last_sched && hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost) == hipSuccess && ctrl[1] != 0) {
         (void)fail(c, PT_ERR_HIP, ctrl[1] == 2 ? "path kernel: dynamic LDS does not start at address 0"

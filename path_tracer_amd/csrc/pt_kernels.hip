@@ -91,21 +91,29 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #endif
 
 
-// Workgroup = 4 waves that share one LDS copy of n0[0 .. lds_nodes) (the top of the
-// tree, breadth-first) and are otherwise independent: one tile each.  n1[] is read
-// through the vector L1, so a node visit puts one 16-byte access on each of the two
-// memory pipes of the CU instead of two on the L1 (the measured bottleneck:
-// profiles/r01).
+// The launch is PERSISTENT: as many workgroups as the chip holds at once (occupancy x CUs), each of 16 waves
+// that share one LDS copy of the top of the tree (breadth-first, lds_nodes nodes) and are otherwise independent:
+// every wave draws (piece, tile) items from one counter until none are left (path_kernel_persistent below).
+// Against one workgroup of 4 waves per 4 items (PT_PERSISTENT=0, the round-1 launch: 516 ms for the headline
+// frame) no wave slot waits for the slowest wave of its group and the tree is staged once per slot instead of
+// once per item: 492 ms at any group size (4, 8, 16 waves).
+#ifndef PT_PERSISTENT
+#define PT_PERSISTENT 1
+#endif
 #ifndef PT_WAVES_PER_GROUP
-#define PT_WAVES_PER_GROUP 4
+#define PT_WAVES_PER_GROUP (PT_PERSISTENT ? 16 : 4)
 #endif
 constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
-// PT_LDS_BOTH (measurement; off): a tree that fits the LDS prefix keeps BOTH halves of its nodes in LDS (n1[] at
-// byte offset PT_LDS_N1_OFFSET of the group's allocation), so that a node visit costs no L1 access at all.  32 KiB
-// per group needs groups of 8 waves to keep 8 waves per SIMD: 561 ms against 583 ms for one LDS + one L1 read at
-// that group size -- and 521 ms for groups of 4 (both halves in LDS with groups of 4: 734 ms, of 16: 631 ms).
+// PT_LDS_BOTH: a tree that fits the LDS prefix keeps BOTH halves of its nodes in LDS (n1[] at byte offset
+// PT_LDS_N1_OFFSET of the group's allocation, 32 KiB per group), so that a node visit costs no vector-memory
+// access at all: 482 ms.  (Without the persistent launch it did not pay: the 8-wave groups it needs to keep 8 waves
+// per SIMD lost more to group tails than the load cost -- 561 ms against 521 ms for groups of 4 with n1[] through
+// the L1.)  A larger tree keeps n0[] of its first lds_nodes nodes in LDS and reads the rest through the L1.
 #ifndef PT_LDS_BOTH
-#define PT_LDS_BOTH 0
+#define PT_LDS_BOTH PT_PERSISTENT
+#endif
+#ifndef PT_SMALL_TREE
+#define PT_SMALL_TREE 32   // nodes; below it the launch without the item loop (launch_path)
 #endif
 #define PT_LDS_N1_OFFSET 16384   // = 16 * kMaxLdsNodes (pt_api.cpp)
 #define PT_STR2(x) #x
@@ -328,6 +336,9 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     uint32_t sxy = ((uint32_t)(s / S) << 16) | (uint32_t)(s % S);
     const bool resume = rp.accumulate || piece > 0;
 
+#ifdef PT_PHASES
+    const unsigned long long tw0 = clock64();
+#endif
     if (piece > 0) {
         // the previous piece of this tile was drawn earlier, by a wave that is running: wait for
         // its sums (agent-scope acquire: cdna_hip_programming.md guideline 16); bounded spin
@@ -340,6 +351,9 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
+#ifdef PT_PHASES
+    if (lane == 0) atomicAdd((unsigned long long *)&sched.ctrl[22], (unsigned long long)(clock64() - tw0));
+#endif
     f3 sum = fill(0.0f);
     if (L == 1 && resume && valid)
         sum = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
@@ -602,7 +616,7 @@ __device__ __forceinline__ bool stage_group(const Scene &sc, const SchedParams &
     if ((uint32_t)(uintptr_t)lds_n0 != 0u) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return false; }
     const int lds_nodes = sc.lds_nodes;
     constexpr bool N1_IN_LDS = PT_LDS_BOTH && ALL_IN_LDS;
-    ticket_slot = N1_IN_LDS ? 2 * (PT_LDS_N1_OFFSET / 16) : lds_nodes;
+    ticket_slot = (N1_IN_LDS ? PT_LDS_N1_OFFSET / 16 : 0) + lds_nodes;
     for (int i = threadIdx.x; i < lds_nodes; i += blockDim.x) {
         lds_n0[i] = sc.n0[i];
         if (N1_IN_LDS) lds_n0[PT_LDS_N1_OFFSET / 16 + i] = sc.n1[i];
@@ -615,12 +629,13 @@ __device__ __forceinline__ bool stage_group(const Scene &sc, const SchedParams &
     return true;
 }
 
-template <bool ALL_IN_LDS, bool EXT = false>
-__global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched,
-                                                                    float *radiance)
+// The launch without the item loop: one workgroup of WPG waves per WPG items.  With PT_PERSISTENT it serves the
+// scenes of a handful of primitives only (launch_path), in groups of 4 waves.
+template <bool ALL_IN_LDS, bool EXT = false, int WPG = WAVES_PER_GROUP>
+__global__ __launch_bounds__(64 * WPG, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched, float *radiance)
 {
     // One ticket per workgroup, drawn while the nodes are staged: the group's waves take the
-    // (piece, tile) items 4*ticket .. 4*ticket+3.  Tickets follow the order in which groups
+    // (piece, tile) items WPG*ticket .. WPG*ticket+WPG-1.  Tickets follow the order in which groups
     // START, so the item a wave may have to wait for (same tile, previous piece: a lower
     // item) belongs to a group that is already running or done -- whatever order the
     // hardware dispatches blockIdx in.
@@ -631,14 +646,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
     __syncthreads();
     const int n_items = sched.n_tiles * sched.n_pieces;
-    const int item = __builtin_amdgcn_readfirstlane(ticket) * WAVES_PER_GROUP + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane(ticket) * WPG + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (item >= n_items) return;
     render_item<ALL_IN_LDS, EXT>(sc, cam, rp, sched, radiance, item, xf_lds);
 }
 
-#ifdef PT_PERSISTENT
-// Persistent variant (measurement): as many workgroups as the chip holds, each wave drawing items until none are
-// left.  The item's code is a real function call, so that nothing of its register allocation leaks into the loop.
+#if PT_PERSISTENT
+// The persistent launch: as many workgroups as the chip holds, each wave drawing items until none are left.  The
+// item's code is a real function call, so that the loop around it takes none of its registers (inlined, the item
+// loop cost 6 % in spilled scalar registers: profiles/r01).
 struct PathArgs { Scene sc; Camera cam; RenderParams rp; SchedParams sched; float *radiance; };
 // The arguments travel as the address of the kernel's own argument block (constant address space, so the
 // function reads them with scalar loads): __builtin_amdgcn_kernarg_segment_ptr() is NULL inside a callee -- the
@@ -647,6 +663,7 @@ typedef __attribute__((address_space(4))) const PathArgs *PathArgsPtr;
 template <bool ALL_IN_LDS, bool EXT>
 __device__ __attribute__((noinline)) void render_item_call(const uint32_t args_lo, const uint32_t args_hi, const int item_v, const uint32_t xf_lds_v)
 {
+#if __HIP_DEVICE_COMPILE__   // the host pass has no address spaces to copy from
     const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)args_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)args_lo);
     const PathArgsPtr a = (PathArgsPtr)addr;
     const int item = __builtin_amdgcn_readfirstlane(item_v);
@@ -656,6 +673,9 @@ __device__ __attribute__((noinline)) void render_item_call(const uint32_t args_l
     const RenderParams rp = a->rp;
     const SchedParams sched = a->sched;
     render_item<ALL_IN_LDS, EXT>(sc, cam, rp, sched, a->radiance, item, xf_lds);
+#else
+    (void)args_lo; (void)args_hi; (void)item_v; (void)xf_lds_v;
+#endif
 }
 template <bool ALL_IN_LDS, bool EXT = false>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel_persistent(PathArgs a)
@@ -665,13 +685,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     __syncthreads();
     const int n_items = a.sched.n_tiles * a.sched.n_pieces;
     const uint64_t args = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // PathArgs is the kernel's only argument: offset 0
+#ifdef PT_PHASES
+    unsigned long long t_draw = 0, t_item = 0;
+#endif
     for (;;) {
         int item = 0;
+#ifdef PT_PHASES
+        const unsigned long long t0 = clock64();
+#endif
         if ((threadIdx.x & 63) == 0) item = atomicAdd(&a.sched.ctrl[0], 1);
         item = __builtin_amdgcn_readfirstlane(item);
+#ifdef PT_PHASES
+        const unsigned long long t1 = clock64();
+        t_draw += t1 - t0;
+#endif
         if (item >= n_items) break;
         render_item_call<ALL_IN_LDS, EXT>((uint32_t)args, (uint32_t)(args >> 32), item, xf_lds);
+#ifdef PT_PHASES
+        t_item += clock64() - t1;
+#endif
     }
+#ifdef PT_PHASES
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)&a.sched.ctrl[16], t_draw);
+        atomicAdd((unsigned long long *)&a.sched.ctrl[18], t_item);
+        atomicAdd((unsigned long long *)&a.sched.ctrl[20], 1ull);
+    }
+#endif
 }
 #endif
 
@@ -904,29 +944,49 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     hipError_t e = hipMemsetAsync(d_sched, 0, sched_bytes(cam), stream);
     if (e != hipSuccess) return e;
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
-    long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
     const bool in_lds = sc.lds_nodes >= sc.n_nodes;
-    const size_t lds_bytes = (PT_LDS_BOTH && in_lds ? 2 * (size_t)PT_LDS_N1_OFFSET + sizeof(float4)
-                                                    : ((size_t)sc.lds_nodes + 1) * sizeof(float4))   // + the ticket word
+    const size_t lds_bytes = (PT_LDS_BOTH && in_lds ? (size_t)PT_LDS_N1_OFFSET : 0) + ((size_t)sc.lds_nodes + 1) * sizeof(float4)   // + the ticket word
                              + (sc.ext ? 2 * (size_t)sc.lds_xforms * sizeof(float4) : 0);
-    const dim3 grid((unsigned)groups), block(64 * WAVES_PER_GROUP);
-#ifdef PT_PERSISTENT
-    if (!sc.ext) {
-        // as many workgroups as the chip holds at once; each wave draws items until none are left
-        const PathArgs args{sc, cam, rp, sp, d_radiance};
-        int per_cu = 0, cus = 0, dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (in_lds) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel_persistent<true, false>, 64 * WAVES_PER_GROUP, lds_bytes);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel_persistent<false, false>, 64 * WAVES_PER_GROUP, lds_bytes);
-        long long resident = (long long)per_cu * cus;
-        if (resident < 1) resident = 1;
-        const dim3 pgrid((unsigned)(groups < resident ? groups : resident));
-        if (in_lds) hipLaunchKernelGGL((path_kernel_persistent<true, false>), pgrid, block, lds_bytes, stream, args);
-        else hipLaunchKernelGGL((path_kernel_persistent<false, false>), pgrid, block, lds_bytes, stream, args);
+#if PT_PERSISTENT
+    // A scene of a handful of primitives keeps the launch of one workgroup of 4 waves per 4 items: its paths are a
+    // segment or two, so what an item costs is set by WHICH tile it is (sky or sphere), the tickets race through
+    // the cheap tiles, and the waves that draw the next pieces of the dear ones stand waiting for their predecessors
+    // (cfg 2, 1920x1080 @ 256 spp: 12.5 ms this way, 17.5 ms with the persistent launch, 11 % of whose wave time is
+    // that wait; the headline frame: 0.02 %).
+    if (!sc.ext && sc.n_nodes < PT_SMALL_TREE) {
+        const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+        if (in_lds) hipLaunchKernelGGL((path_kernel<true, false, 4>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+        else hipLaunchKernelGGL((path_kernel<false, false, 4>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
         return hipGetLastError();
     }
 #endif
+    const long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
+    const dim3 block(64 * WAVES_PER_GROUP);
+#if PT_PERSISTENT
+    {
+        // as many workgroups as the chip holds at once; each wave draws items until none are left
+        const PathArgs args{sc, cam, rp, sp, d_radiance};
+        int per_cu = 0, cus = 0, dev = 0;
+        hipError_t q = hipGetDevice(&dev);
+        if (q == hipSuccess) q = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (q != hipSuccess) return q;
+        const void *fn = nullptr;
+        if (!sc.ext) fn = in_lds ? (const void *)path_kernel_persistent<true, false> : (const void *)path_kernel_persistent<false, false>;
+#ifndef PT_FAST_MODE
+        else fn = in_lds ? (const void *)path_kernel_persistent<true, true> : (const void *)path_kernel_persistent<false, true>;
+#else
+        else return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
+#endif
+        q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WAVES_PER_GROUP, lds_bytes);
+        if (q != hipSuccess) return q;
+        long long resident = (long long)per_cu * cus;
+        if (resident < 1) resident = 1;
+        const dim3 pgrid((unsigned)(groups < resident ? groups : resident));
+        void *kargs[] = {(void *)&args};
+        return hipLaunchKernel(fn, pgrid, block, kargs, lds_bytes, stream);
+    }
+#else
+    const dim3 grid((unsigned)groups);
     if (!sc.ext) {
         if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
         else hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
@@ -939,6 +999,7 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
 #endif
     }
     return hipGetLastError();
+#endif
 }
 
 #ifndef PT_FAST_MODE

@@ -8,6 +8,7 @@ rev=$(echo "$names" | tac)
 for n in $names $rev; do
   r=$(PT_AMD_LIB=$REPO/build/variants/$n.so timeout -k 10 120 python3 $REPO/bench.py --no-cpu-baseline "$@" 2>/dev/null | grep -o 'kernel_ms": [0-9.]*' | grep -o '[0-9.]*$')
   echo "$n ${r:-failed}"
+  [ -z "$r" ] && break   # a failed run may have been a GPU fault: nothing more runs in this call
 done | python3 -c '
 import sys
 best = {}
