@@ -241,7 +241,7 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
     uint64_t save, cur; int cnt;
 #define PT_RUN_TEST_FAST \
     "v_fma_f32 v48, v48, %[ix], %[nx]\n v_fma_f32 v49, v49, %[iy], %[ny]\n v_fma_f32 v50, v50, %[iz], %[nz]\n" \
-    "s_waitcnt vmcnt(0)\n" \
+    PT_RUN_WAIT_B \
     "v_fma_f32 v52, v52, %[ix], %[nx]\n v_fma_f32 v53, v53, %[iy], %[ny]\n v_fma_f32 v54, v54, %[iz], %[nz]\n" \
     "v_med3_f32 v56, v48, v52, %[tmin]\n v_med3_f32 v57, %[t], v48, v52\n" \
     "v_med3_f32 v56, v56, v49, v53\n v_med3_f32 v57, v57, v49, v53\n" \
@@ -253,9 +253,15 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
     if (ALL_IN_LDS) {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUNF%=:\n"
+#if PT_LDS_BOTH
+                     "ds_read_b128 v[48:51], %[code]\n"
+                     "ds_read_b128 v[52:55], %[code] offset:" PT_STR(PT_LDS_N1_OFFSET) "\n"
+                     "s_waitcnt lgkmcnt(1)\n"
+#else
                      "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
                      "ds_read_b128 v[48:51], %[code]\n"
                      "s_waitcnt lgkmcnt(0)\n"
+#endif
                      PT_RUN_TEST_FAST
                      "s_cbranch_execnz .LPTRUNF%=\n"
                      "s_mov_b64 exec, %[save]\n"
