@@ -23,7 +23,7 @@ thread_local std::string g_create_error;
 constexpr int64_t kFullChipLanes = 256ll * 4 * 8 * 64;
 // n0[] entries (16 B each) a workgroup stages in LDS: 16 KiB, so LDS (160 KiB per CU)
 // never limits residency below the 8 workgroups x 4 waves a CU can hold
-constexpr int32_t kMaxLdsNodes = 1024;
+constexpr int32_t kMaxLdsNodes = 2048;   // = PT_LDS_N1_OFFSET / 16 (pt_kernels.hip): both halves of these nodes sit in LDS, 64 KiB per group
 
 }  // namespace
 

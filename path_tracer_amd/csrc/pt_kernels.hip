@@ -1,8 +1,8 @@
 // pt_kernels.hip -- gfx950 kernels of the radiance hot path and their launchers.
 //
 //   K1 primary_hit_kernel : camera.ray + Scene::trace for one sample index (AOV)
-//   K2 path_kernel        : trace_pixel + trace_ray and everything below
-//                           (src/raytracer.rs:46-96), one lane per (pixel, sample chunk)
+//   K2 path_kernel_persistent (path_kernel for trees of a few nodes): trace_pixel + trace_ray and
+//                           everything below (src/raytracer.rs:46-96), one lane per (pixel, sample chunk)
 //   K3 resolve_kernel     : sqrt(sum / S^2) * 255 -> u8 (src/raytracer.rs:92-93,119-121)
 //
 // Compiled with -ffp-contract=off (see pt_device.hpp).
@@ -24,6 +24,7 @@ using namespace ptd;
 #endif
 #define PTK ptk_fast
 #define path_kernel path_kernel_fast   // its own name in profiles
+#define path_kernel_persistent path_kernel_persistent_fast
 #else
 #define PTK ptk
 #endif
@@ -94,28 +95,26 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 // The launch is PERSISTENT: as many workgroups as the chip holds at once (occupancy x CUs), each of 16 waves
 // that share one LDS copy of the top of the tree (breadth-first, lds_nodes nodes) and are otherwise independent:
 // every wave draws (piece, tile) items from one counter until none are left (path_kernel_persistent below).
-// Against one workgroup of 4 waves per 4 items (PT_PERSISTENT=0, the round-1 launch: 516 ms for the headline
-// frame) no wave slot waits for the slowest wave of its group and the tree is staged once per slot instead of
-// once per item: 492 ms at any group size (4, 8, 16 waves).
-#ifndef PT_PERSISTENT
-#define PT_PERSISTENT 1
-#endif
+// Against one workgroup of 4 waves per 4 items (the round-1 launch: 516 ms for the headline frame) no wave slot
+// waits for the slowest wave of its group and the tree is staged once per slot instead of once per item: 492 ms
+// at any group size (4, 8, 16 waves).
 #ifndef PT_WAVES_PER_GROUP
-#define PT_WAVES_PER_GROUP (PT_PERSISTENT ? 16 : 4)
+#define PT_WAVES_PER_GROUP 16
 #endif
 constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
-// PT_LDS_BOTH: a tree that fits the LDS prefix keeps BOTH halves of its nodes in LDS (n1[] at byte offset
-// PT_LDS_N1_OFFSET of the group's allocation, 32 KiB per group), so that a node visit costs no vector-memory
-// access at all: 482 ms.  (Without the persistent launch it did not pay: the 8-wave groups it needs to keep 8 waves
-// per SIMD lost more to group tails than the load cost -- 561 ms against 521 ms for groups of 4 with n1[] through
-// the L1.)  A larger tree keeps n0[] of its first lds_nodes nodes in LDS and reads the rest through the L1.
-#ifndef PT_LDS_BOTH
-#define PT_LDS_BOTH PT_PERSISTENT
-#endif
+// BOTH halves of a staged node sit in LDS -- n0[] from byte 0, n1[] from byte N1OFF of the group's allocation (a
+// template parameter: PT_LDS_N1_OFFSET for the persistent launch, PT_SMALL_N1_OFFSET for the small-tree one) -- so
+// a visit of a staged node makes no vector-memory access at all: 482 ms.  (Without the persistent launch it did
+// not pay: the 8-wave groups it needs to keep 8 waves per SIMD lost more to group tails than the load cost -- 561
+// ms against 521 ms for groups of 4 with n1[] through the L1.)  A tree of more than PT_LDS_N1_OFFSET / 16 nodes
+// keeps that many, its top breadth-first, in LDS and reads both halves of the others through the L1: a 16-byte
+// gather costs the CU 10 + 0.85 cycles per ENABLED lane (tools/ubench/vmem_sparse.hip), so the lanes standing on
+// staged nodes -- 85 % of the visits of cfg 5's 21,385-node tree -- are left out of it.
 #ifndef PT_SMALL_TREE
 #define PT_SMALL_TREE 32   // nodes; below it the launch without the item loop (launch_path)
 #endif
-#define PT_LDS_N1_OFFSET 16384   // = 16 * kMaxLdsNodes (pt_api.cpp)
+#define PT_LDS_N1_OFFSET 32768   // = 16 * kMaxLdsNodes (pt_api.cpp)
+#define PT_SMALL_N1_OFFSET (16 * PT_SMALL_TREE)
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
 #ifndef PT_MIN_WAVES
@@ -128,11 +127,11 @@ constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
 // restored on exit.  21 (ALL_IN_LDS) / 22 VALU + 3 / 8 SALU + one branch per node, against the
 // compiler's 23 + 7 for the same C++ loop: the scalar unit is shared by the CU's four SIMDs, so
 // loop control costs as much as arithmetic (tools/ubench/salu_rate.hip).  -5 %.
-//   n1 (bmax, next code) comes through the L1; n0 (bmin, skip code) from LDS -- for the lanes
-//   inside the staged prefix when the tree is larger than it, through the L1 for the others,
-//   that load skipped when no lane needs it.
+//   Both halves of a staged node come from LDS (n0 at the node's code, n1 N1OFF bytes behind it); when the
+//   tree is larger than the staged prefix, the lanes outside it read both halves through the L1, under their
+//   own exec mask, and those loads are skipped when no lane needs them.
 // The arithmetic is split_step<true>'s, instruction for instruction; v48-v57 are scratch.
-template <bool ALL_IN_LDS>
+template <bool ALL_IN_LDS, int N1OFF>
 __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, const f3 inv, const float closest, const Scene &sc,
                                                      const int n_split_end, const int keep)
 {
@@ -144,11 +143,10 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
 // Scratch registers of the run: A = n0 (v48-51), B = n1 (v52-55), E / F = the tmin / tmax chains (v56, v57).
 // Each pair (n0.k, n1.k) shares a VGPR bank (register number mod 4); a layout in which no instruction reads two
 // scratch registers of one bank (A = v46-49, B = v52-55, E = v51, F = v57, chains y, x, z) measured the same
-// (520.6 vs 521.0 ms): operand banks do not limit this loop.  What an instruction MORE in this loop costs, each
-// measured by adding one (522 ms frame): a vector-memory load of any width +110 ms (the same 16 bytes as a 12- and
-// a 4-byte load: 632 ms) -- the CU's address unit takes every lane's address, whatever the width; an LDS read of
-// 4, 8 or 16 bytes: nothing (522-526 ms).  Taking the one vector-memory load OUT (PT_LDS_BOTH) gains only 22 ms at
-// equal group size, less than the 62 ms the larger groups it needs cost.
+// (520.6 vs 521.0 ms): operand banks do not limit this loop.  What an instruction MORE in this loop cost, each
+// measured by adding one to the 522 ms frame of the launch that read n1 through the L1: a vector-memory load of
+// any width +110 ms (the same 16 bytes as a 12- and a 4-byte load: 632 ms); an LDS read of 4, 8 or 16 bytes:
+// nothing (522-526 ms).
 #define RA0 "v48"
 #define RA1 "v49"
 #define RA2 "v50"
@@ -166,15 +164,10 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
     "v_med3_f32 " RE ", " RA0 ", " RB0 ", %[tmin]\n v_med3_f32 " RF ", %[t], " RA0 ", " RB0 "\n" \
     "v_med3_f32 " RE ", " RE ", " RA1 ", " RB1 "\n v_med3_f32 " RF ", " RF ", " RA1 ", " RB1 "\n" \
     "v_med3_f32 " RE ", " RE ", " RA2 ", " RB2 "\n v_med3_f32 " RF ", " RF ", " RA2 ", " RB2 "\n"
-#if PT_LDS_BOTH
-#define PT_RUN_WAIT_B "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-#else
-#define PT_RUN_WAIT_B "s_waitcnt vmcnt(0)\n"
-#endif
 #define PT_RUN_TEST \
     "v_sub_f32 " RA0 ", " RA0 ", %[ox]\n v_sub_f32 " RA1 ", " RA1 ", %[oy]\n v_sub_f32 " RA2 ", " RA2 ", %[oz]\n" \
     "v_mul_f32 " RA0 ", %[ix], " RA0 "\n v_mul_f32 " RA1 ", %[iy], " RA1 "\n v_mul_f32 " RA2 ", %[iz], " RA2 "\n" \
-    PT_RUN_WAIT_B \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
     "v_sub_f32 " RB0 ", " RB0 ", %[ox]\n v_sub_f32 " RB1 ", " RB1 ", %[oy]\n v_sub_f32 " RB2 ", " RB2 ", %[oz]\n" \
     "v_mul_f32 " RB0 ", %[ix], " RB0 "\n v_mul_f32 " RB1 ", %[iy], " RB1 "\n v_mul_f32 " RB2 ", %[iz], " RB2 "\n" \
     PT_RUN_CHAINS \
@@ -185,34 +178,29 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
     if (ALL_IN_LDS) {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUN%=:\n"
-#if PT_LDS_BOTH
                      "ds_read_b128 " RA ", %[code]\n"
-                     "ds_read_b128 " RB ", %[code] offset:" PT_STR(PT_LDS_N1_OFFSET) "\n"
+                     "ds_read_b128 " RB ", %[code] offset:%[n1off]\n"
                      "s_waitcnt lgkmcnt(1)\n"
-#else
-                     "buffer_load_dwordx4 " RB ", %[code], %[rs1], 0 offen\n"
-                     "ds_read_b128 " RA ", %[code]\n"
-                     "s_waitcnt lgkmcnt(0)\n"
-#endif
                      PT_RUN_TEST
                      "s_cbranch_execnz .LPTRUN%=\n"
                      "s_mov_b64 exec, %[save]\n"
                      : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
                      : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
-                       [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep)
+                       [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep), [n1off] "i"(N1OFF)
                      : "vcc", "scc", "memory", PT_RUN_CLOBBERS);
     } else {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUN%=:\n"
                      "v_cmp_gt_u32 vcc, %[lim], %[code]\n"
                      "s_mov_b64 %[cur], exec\n"
-                     "buffer_load_dwordx4 " RB ", %[code], %[rs1], 0 offen\n"
                      "s_andn2_b64 exec, %[cur], vcc\n"
                      "s_cbranch_execz .LPTNODEEP%=\n"
+                     "buffer_load_dwordx4 " RB ", %[code], %[rs1], 0 offen\n"
                      "buffer_load_dwordx4 " RA ", %[code], %[rs0], 0 offen\n"
                      ".LPTNODEEP%=:\n"
                      "s_and_b64 exec, %[cur], vcc\n"
                      "ds_read_b128 " RA ", %[code]\n"
+                     "ds_read_b128 " RB ", %[code] offset:%[n1off]\n"
                      "s_mov_b64 exec, %[cur]\n"
                      "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
                      PT_RUN_TEST
@@ -221,16 +209,17 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
                      : [code] "+v"(code), [save] "=&s"(save), [cur] "=&s"(cur), [cnt] "=&s"(cnt)
                      : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
                        [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
-                       [lim] "s"(sc.lds_nodes << 4)
+                       [lim] "s"(sc.lds_nodes << 4), [n1off] "i"(N1OFF)
                      : "vcc", "scc", "memory", PT_RUN_CLOBBERS);
     }
 #undef PT_RUN_TEST
+    (void)rs0; (void)rs1; (void)cur;
     return code;
 }
 
 #ifdef PT_FAST_MODE
 // The SPLIT run of the FAST build: one v_fma_f32 per plane (pt_device.hpp split_step_fast): 15 VALU per node.
-template <bool ALL_IN_LDS>
+template <bool ALL_IN_LDS, int N1OFF>
 __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3 inv, const f3 noi, const float closest, const Scene &sc,
                                                           const int n_split_end, const int keep)
 {
@@ -241,7 +230,7 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
     uint64_t save, cur; int cnt;
 #define PT_RUN_TEST_FAST \
     "v_fma_f32 v48, v48, %[ix], %[nx]\n v_fma_f32 v49, v49, %[iy], %[ny]\n v_fma_f32 v50, v50, %[iz], %[nz]\n" \
-    PT_RUN_WAIT_B \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
     "v_fma_f32 v52, v52, %[ix], %[nx]\n v_fma_f32 v53, v53, %[iy], %[ny]\n v_fma_f32 v54, v54, %[iz], %[nz]\n" \
     "v_med3_f32 v56, v48, v52, %[tmin]\n v_med3_f32 v57, %[t], v48, v52\n" \
     "v_med3_f32 v56, v56, v49, v53\n v_med3_f32 v57, v57, v49, v53\n" \
@@ -253,34 +242,29 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
     if (ALL_IN_LDS) {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUNF%=:\n"
-#if PT_LDS_BOTH
                      "ds_read_b128 v[48:51], %[code]\n"
-                     "ds_read_b128 v[52:55], %[code] offset:" PT_STR(PT_LDS_N1_OFFSET) "\n"
+                     "ds_read_b128 v[52:55], %[code] offset:%[n1off]\n"
                      "s_waitcnt lgkmcnt(1)\n"
-#else
-                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
-                     "ds_read_b128 v[48:51], %[code]\n"
-                     "s_waitcnt lgkmcnt(0)\n"
-#endif
                      PT_RUN_TEST_FAST
                      "s_cbranch_execnz .LPTRUNF%=\n"
                      "s_mov_b64 exec, %[save]\n"
                      : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
                      : [nx] "v"(noi.x), [ny] "v"(noi.y), [nz] "v"(noi.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
-                       [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep)
+                       [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep), [n1off] "i"(N1OFF)
                      : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
     } else {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUNF%=:\n"
                      "v_cmp_gt_u32 vcc, %[lim], %[code]\n"
                      "s_mov_b64 %[cur], exec\n"
-                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
                      "s_andn2_b64 exec, %[cur], vcc\n"
                      "s_cbranch_execz .LPTNODEEPF%=\n"
+                     "buffer_load_dwordx4 v[52:55], %[code], %[rs1], 0 offen\n"
                      "buffer_load_dwordx4 v[48:51], %[code], %[rs0], 0 offen\n"
                      ".LPTNODEEPF%=:\n"
                      "s_and_b64 exec, %[cur], vcc\n"
                      "ds_read_b128 v[48:51], %[code]\n"
+                     "ds_read_b128 v[52:55], %[code] offset:%[n1off]\n"
                      "s_mov_b64 exec, %[cur]\n"
                      "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
                      PT_RUN_TEST_FAST
@@ -289,17 +273,18 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
                      : [code] "+v"(code), [save] "=&s"(save), [cur] "=&s"(cur), [cnt] "=&s"(cnt)
                      : [nx] "v"(noi.x), [ny] "v"(noi.y), [nz] "v"(noi.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
                        [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
-                       [lim] "s"(sc.lds_nodes << 4)
+                       [lim] "s"(sc.lds_nodes << 4), [n1off] "i"(N1OFF)
                      : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
     }
 #undef PT_RUN_TEST_FAST
+    (void)rs0; (void)rs1; (void)cur;
     return code;
 }
 #endif
 
 // One (piece, tile) item, rendered by one wave.  The kernels below hand the items out: path_kernel one per wave
 // of a workgroup that then ends, path_kernel_persistent in a loop.
-template <bool ALL_IN_LDS, bool EXT>
+template <bool ALL_IN_LDS, bool EXT, int N1OFF>
 __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, const RenderParams &rp, const SchedParams &sched,
                                             float *radiance, const int item, const uint32_t xf_lds)
 {
@@ -308,7 +293,6 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     typedef __attribute__((address_space(3))) const v4f lds_f4;
     auto lds_read = [](uint32_t addr) -> float4 { const v4f t = *(lds_f4 *)(uintptr_t)addr; return make_float4(t.x, t.y, t.z, t.w); };
     const int lds_nodes = sc.lds_nodes;
-    constexpr bool N1_IN_LDS = PT_LDS_BOTH && ALL_IN_LDS;
     (void)xf_lds;
     const int lane = threadIdx.x & 63;
     const int L = rp.lanes;
@@ -383,18 +367,19 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     uint64_t rng = 0;
     bool regular = true;
 
-    // n1[i] through the L1 (one 32-bit byte offset serves both arrays), n0[i] from LDS when staged
+    // both halves of a staged node from LDS, of any other node through the L1 (one 32-bit byte offset serves all)
     // SPLIT_ONLY: the caller knows c is a Split code (no Leaf flag to mask)
     auto fetch = [&](int32_t c, float4 &n0, float4 &n1, const bool SPLIT_ONLY = false) {
         const int off = SPLIT_ONLY ? (c << (4 - PT_CODE_SHIFT)) : code_offset(c);
-        if (N1_IN_LDS) n1 = lds_read((uint32_t)off + PT_LDS_N1_OFFSET);
-        else {
+        if (ALL_IN_LDS || off < (lds_nodes << 4)) {
+            n0 = lds_read((uint32_t)off);
+            n1 = lds_read((uint32_t)off + (uint32_t)N1OFF);
+            if (!ALL_IN_LDS) asm volatile("" : "+v"(n0.x), "+v"(n1.x));
+        } else {
             const auto raw = __builtin_amdgcn_raw_buffer_load_b128(n1_rsrc, off, 0, 0);
             n1 = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+            n0 = *(const float4 *)((const char *)sc.n0 + off);
         }
-        if (ALL_IN_LDS) n0 = lds_read((uint32_t)off);
-        else if (off < (lds_nodes << 4)) { n0 = lds_read((uint32_t)off); asm volatile("" : "+v"(n0.x)); }
-        else n0 = *(const float4 *)((const char *)sc.n0 + off);
     };
     auto lanes = [&](bool p) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(p))); };
 
@@ -471,10 +456,10 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
                 if ((uint32_t)code < (uint32_t)n_nodes) {
                     if (all_regular) {
 #if defined(PT_FAST_MODE) && PT_FAST_BOX
-                        if (all_fma_ok) code = split_run_regular_fast<ALL_IN_LDS>(code, inv, noi, h.t, sc, n_nodes, keep);
-                        else code = split_run_regular<ALL_IN_LDS>(code, ray.o, inv, h.t, sc, n_nodes, keep);
+                        if (all_fma_ok) code = split_run_regular_fast<ALL_IN_LDS, N1OFF>(code, inv, noi, h.t, sc, n_nodes, keep);
+                        else code = split_run_regular<ALL_IN_LDS, N1OFF>(code, ray.o, inv, h.t, sc, n_nodes, keep);
 #elif !defined(PT_STATS)
-                        code = split_run_regular<ALL_IN_LDS>(code, ray.o, inv, h.t, sc, n_nodes, keep);
+                        code = split_run_regular<ALL_IN_LDS, N1OFF>(code, ray.o, inv, h.t, sc, n_nodes, keep);
 #else   // the same run in C++, with its step counters
                         for (;;) {
                             PT_STAT(0, lanes(true));
@@ -612,20 +597,20 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
 // EXT: the instantiation for scenes uploaded with pt_upload_scene_ext (rects, instances, lights, integrator
 // options).  The reference's scenes always run EXT = false, whose code is unchanged.
 // Stages the group's LDS copy of the nodes (and transforms); returns the LDS address of the transform table.
-template <bool ALL_IN_LDS, bool EXT>
+template <bool EXT, int N1OFF>
 __device__ __forceinline__ bool stage_group(const Scene &sc, const SchedParams &sched, uint32_t &xf_lds, int &ticket_slot)
 {
-    // dynamic LDS: n0[0 .. lds_nodes) then the group's ticket.  There is no static __shared__
-    // in this kernel, so the array starts at LDS address 0 and 16 * slot IS the LDS address of
+    // dynamic LDS: n0[0 .. lds_nodes), n1[0 .. lds_nodes) from byte N1OFF, then the group's ticket.  There is no
+    // static __shared__ in this kernel, so the array starts at LDS address 0 and 16 * slot IS the LDS address of
     // a node's n0 entry: no base add per node visit (checked here: error flag 2).
     extern __shared__ float4 lds_n0[];
     if ((uint32_t)(uintptr_t)lds_n0 != 0u) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return false; }
     const int lds_nodes = sc.lds_nodes;
-    constexpr bool N1_IN_LDS = PT_LDS_BOTH && ALL_IN_LDS;
-    ticket_slot = (N1_IN_LDS ? PT_LDS_N1_OFFSET / 16 : 0) + lds_nodes;
+    if (lds_nodes * 16 > N1OFF) { if (threadIdx.x == 0) sched.ctrl[1] = 2; return false; }   // launch_path never asks for this
+    ticket_slot = N1OFF / 16 + lds_nodes;
     for (int i = threadIdx.x; i < lds_nodes; i += blockDim.x) {
         lds_n0[i] = sc.n0[i];
-        if (N1_IN_LDS) lds_n0[PT_LDS_N1_OFFSET / 16 + i] = sc.n1[i];
+        lds_n0[N1OFF / 16 + i] = sc.n1[i];
     }
     // extension scenes: the instance transforms (two float4 each) behind the ticket word
     const int xf_slot = ticket_slot + 1;
@@ -634,30 +619,34 @@ __device__ __forceinline__ bool stage_group(const Scene &sc, const SchedParams &
         for (int i = threadIdx.x; i < 2 * sc.lds_xforms; i += blockDim.x) lds_n0[xf_slot + i] = sc.xforms[i];
     return true;
 }
+// bytes of dynamic LDS stage_group fills
+static size_t group_lds_bytes(const Scene &sc, int n1off)
+{
+    return (size_t)n1off + ((size_t)sc.lds_nodes + 1) * sizeof(float4) + (sc.ext ? 2 * (size_t)sc.lds_xforms * sizeof(float4) : 0);
+}
 
-// The launch without the item loop: one workgroup of WPG waves per WPG items.  With PT_PERSISTENT it serves the
-// scenes of a handful of primitives only (launch_path), in groups of 4 waves.
-template <bool ALL_IN_LDS, bool EXT = false, int WPG = WAVES_PER_GROUP>
-__global__ __launch_bounds__(64 * WPG, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched, float *radiance)
+// The launch without the item loop: one workgroup of 4 waves per 4 items.  It serves the scenes of a handful of
+// primitives only (launch_path).
+template <bool EXT = false>
+__global__ __launch_bounds__(256, PT_MIN_WAVES) void path_kernel(Scene sc, Camera cam, RenderParams rp, SchedParams sched, float *radiance)
 {
     // One ticket per workgroup, drawn while the nodes are staged: the group's waves take the
-    // (piece, tile) items WPG*ticket .. WPG*ticket+WPG-1.  Tickets follow the order in which groups
+    // (piece, tile) items 4*ticket .. 4*ticket+3.  Tickets follow the order in which groups
     // START, so the item a wave may have to wait for (same tile, previous piece: a lower
     // item) belongs to a group that is already running or done -- whatever order the
     // hardware dispatches blockIdx in.
     extern __shared__ float4 lds_n0[];
     uint32_t xf_lds; int ticket_slot;
-    if (!stage_group<ALL_IN_LDS, EXT>(sc, sched, xf_lds, ticket_slot)) return;
+    if (!stage_group<EXT, PT_SMALL_N1_OFFSET>(sc, sched, xf_lds, ticket_slot)) return;
     int &ticket = *(int *)&lds_n0[ticket_slot];
     if (threadIdx.x == 0) ticket = atomicAdd(&sched.ctrl[0], 1);
     __syncthreads();
     const int n_items = sched.n_tiles * sched.n_pieces;
-    const int item = __builtin_amdgcn_readfirstlane(ticket) * WPG + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane(ticket) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (item >= n_items) return;
-    render_item<ALL_IN_LDS, EXT>(sc, cam, rp, sched, radiance, item, xf_lds);
+    render_item<true, EXT, PT_SMALL_N1_OFFSET>(sc, cam, rp, sched, radiance, item, xf_lds);
 }
 
-#if PT_PERSISTENT
 // The persistent launch: as many workgroups as the chip holds, each wave drawing items until none are left.  The
 // item's code is a real function call, so that the loop around it takes none of its registers (inlined, the item
 // loop cost 6 % in spilled scalar registers: profiles/r01).
@@ -678,7 +667,7 @@ __device__ __attribute__((noinline)) void render_item_call(const uint32_t args_l
     const Camera cam = a->cam;
     const RenderParams rp = a->rp;
     const SchedParams sched = a->sched;
-    render_item<ALL_IN_LDS, EXT>(sc, cam, rp, sched, a->radiance, item, xf_lds);
+    render_item<ALL_IN_LDS, EXT, PT_LDS_N1_OFFSET>(sc, cam, rp, sched, a->radiance, item, xf_lds);
 #else
     (void)args_lo; (void)args_hi; (void)item_v; (void)xf_lds_v;
 #endif
@@ -687,7 +676,7 @@ template <bool ALL_IN_LDS, bool EXT = false>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel_persistent(PathArgs a)
 {
     uint32_t xf_lds; int ticket_slot;
-    if (!stage_group<ALL_IN_LDS, EXT>(a.sc, a.sched, xf_lds, ticket_slot)) return;
+    if (!stage_group<EXT, PT_LDS_N1_OFFSET>(a.sc, a.sched, xf_lds, ticket_slot)) return;
     __syncthreads();
     const int n_items = a.sched.n_tiles * a.sched.n_pieces;
     const uint64_t args = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // PathArgs is the kernel's only argument: offset 0
@@ -719,7 +708,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     }
 #endif
 }
-#endif
 
 #ifndef PT_FAST_MODE   // everything from here to the launchers is built once, in the EXACT translation unit
 // K1: primitive id (and t) hit by the primary ray of one sample index.
@@ -951,9 +939,6 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     if (e != hipSuccess) return e;
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     const bool in_lds = sc.lds_nodes >= sc.n_nodes;
-    const size_t lds_bytes = (PT_LDS_BOTH && in_lds ? (size_t)PT_LDS_N1_OFFSET : 0) + ((size_t)sc.lds_nodes + 1) * sizeof(float4)   // + the ticket word
-                             + (sc.ext ? 2 * (size_t)sc.lds_xforms * sizeof(float4) : 0);
-#if PT_PERSISTENT
     // A scene of a handful of primitives keeps the launch of one workgroup of 4 waves per 4 items: its paths are a
     // segment or two, so what an item costs is set by WHICH tile it is (sky or sphere), the tickets race through
     // the cheap tiles, and the waves that draw the next pieces of the dear ones stand waiting for their predecessors
@@ -961,51 +946,37 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     // that wait; the headline frame: 0.02 %).
     if (!sc.ext && sc.n_nodes < PT_SMALL_TREE) {
         const dim3 grid((unsigned)((items + 3) / 4)), block(256);
-        if (in_lds) hipLaunchKernelGGL((path_kernel<true, false, 4>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
-        else hipLaunchKernelGGL((path_kernel<false, false, 4>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
+        hipLaunchKernelGGL((path_kernel<false>), grid, block, group_lds_bytes(sc, PT_SMALL_N1_OFFSET), stream, sc, cam, rp, sp, d_radiance);
         return hipGetLastError();
     }
-#endif
+    if (sc.lds_nodes * 16 > PT_LDS_N1_OFFSET) return hipErrorInvalidValue;   // pt_api.cpp stages at most kMaxLdsNodes
+    const size_t lds_bytes = group_lds_bytes(sc, PT_LDS_N1_OFFSET);
     const long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
     const dim3 block(64 * WAVES_PER_GROUP);
-#if PT_PERSISTENT
-    {
-        // as many workgroups as the chip holds at once; each wave draws items until none are left
-        const PathArgs args{sc, cam, rp, sp, d_radiance};
-        int per_cu = 0, cus = 0, dev = 0;
-        hipError_t q = hipGetDevice(&dev);
-        if (q == hipSuccess) q = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (q != hipSuccess) return q;
-        const void *fn = nullptr;
-        if (!sc.ext) fn = in_lds ? (const void *)path_kernel_persistent<true, false> : (const void *)path_kernel_persistent<false, false>;
+    // as many workgroups as the chip holds at once; each wave draws items until none are left
+    const PathArgs args{sc, cam, rp, sp, d_radiance};
+    int per_cu = 0, cus = 0, dev = 0;
+    hipError_t q = hipGetDevice(&dev);
+    if (q == hipSuccess) q = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (q != hipSuccess) return q;
+    const void *fn = nullptr;
+    if (!sc.ext) fn = in_lds ? (const void *)path_kernel_persistent<true, false> : (const void *)path_kernel_persistent<false, false>;
 #ifndef PT_FAST_MODE
-        else fn = in_lds ? (const void *)path_kernel_persistent<true, true> : (const void *)path_kernel_persistent<false, true>;
+    else fn = in_lds ? (const void *)path_kernel_persistent<true, true> : (const void *)path_kernel_persistent<false, true>;
 #else
-        else return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
+    else return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
 #endif
-        q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WAVES_PER_GROUP, lds_bytes);
+    if (lds_bytes > 48 * 1024) {   // beyond the default cap on dynamic LDS per workgroup (a tree of more than 1023 nodes)
+        q = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (q != hipSuccess) return q;
-        long long resident = (long long)per_cu * cus;
-        if (resident < 1) resident = 1;
-        const dim3 pgrid((unsigned)(groups < resident ? groups : resident));
-        void *kargs[] = {(void *)&args};
-        return hipLaunchKernel(fn, pgrid, block, kargs, lds_bytes, stream);
     }
-#else
-    const dim3 grid((unsigned)groups);
-    if (!sc.ext) {
-        if (in_lds) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
-        else hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
-    } else {
-#ifndef PT_FAST_MODE
-        if (in_lds) hipLaunchKernelGGL((path_kernel<true, true>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
-        else hipLaunchKernelGGL((path_kernel<false, true>), grid, block, lds_bytes, stream, sc, cam, rp, sp, d_radiance);
-#else
-        return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
-#endif
-    }
-    return hipGetLastError();
-#endif
+    q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WAVES_PER_GROUP, lds_bytes);
+    if (q != hipSuccess) return q;
+    long long resident = (long long)per_cu * cus;
+    if (resident < 1) resident = 1;
+    const dim3 pgrid((unsigned)(groups < resident ? groups : resident));
+    void *kargs[] = {(void *)&args};
+    return hipLaunchKernel(fn, pgrid, block, kargs, lds_bytes, stream);
 }
 
 #ifndef PT_FAST_MODE
