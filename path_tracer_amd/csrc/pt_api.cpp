@@ -173,8 +173,9 @@ bool boxes_contain(const pt_bvh_node *nodes, int32_t n_nodes, const pt_primitive
 // reference's choice.  Extension scenes (coplanar rects tie by construction, and rect_step has no such
 // rule) always keep the reference's order, and so do trees whose boxes do not contain what is below them
 // (boxes_contain): there a box test can hide a closer hit and the order of the walk decides which.
-// Slots: the first kMaxLdsNodes nodes breadth-first (the top of the tree -- visited by every ray -- is the prefix
-// the path kernel keeps in LDS), the others in walk order (a Split's first child is the next entry: neighbouring
+// Slots: kMaxLdsNodes nodes are the prefix the path kernel keeps in LDS -- the first ones breadth-first (the top of
+// the tree, visited by every ray) or, in the view order, the ones this camera's walks visit most --, the others
+// follow in walk order (a Split's first child is the next entry: neighbouring
 // entries share cache lines; -0.8 % on cfg 5 against breadth-first throughout).
 int thread_nodes(pt_context *c)
 {
@@ -255,8 +256,44 @@ int thread_nodes(pt_context *c)
         } catch (...) {
             return fail(c, PT_ERR_INVALID, "out of host memory");
         }
-        for (int32_t q = 0; q < kMaxLdsNodes; q++) { slot[order[q]] = q; in_prefix[order[q]] = 1; }
-        int32_t next_slot = kMaxLdsNodes;
+        if (!view) {
+            for (int32_t q = 0; q < kMaxLdsNodes; q++) in_prefix[order[q]] = 1;
+        } else {
+            // The nodes a walk from this camera visits most: a node is visited when its parent's box is hit, and
+            // seen from the eye that box subtends about area / distance^2.  On cfg 5 (21,385 nodes) the 2048 nodes
+            // of largest key take 94.4 % of the visits, the first 2048 breadth-first 85.5 %
+            // (tests/experiments/exp_prefix.c).  Placement only: no result depends on it.
+            std::vector<double> key;
+            std::vector<int32_t> pick;
+            try {
+                key.assign((size_t)n_nodes, 0.0);
+                pick.resize((size_t)n_nodes);
+            } catch (...) {
+                return fail(c, PT_ERR_INVALID, "out of host memory");
+            }
+            auto key_of_parent = [&](int32_t p) -> double {
+                const double ex = (double)nodes[p].bmax[0] - (double)nodes[p].bmin[0], ey = (double)nodes[p].bmax[1] - (double)nodes[p].bmin[1],
+                             ez = (double)nodes[p].bmax[2] - (double)nodes[p].bmin[2];
+                const double k = (ex * ey + ey * ez + ez * ex) / (dist2(p) + 1e-30);
+                return k == k ? k : -1.0;               // a NaN box sorts last
+            };
+            key[0] = key_of_parent(0);
+            for (int32_t i = 0; i < n_nodes; i++) {
+                pick[(size_t)i] = i;
+                if (nodes[i].prim >= 0) continue;
+                const double k = key_of_parent(i);
+                key[(size_t)i + 1] = k;
+                key[(size_t)nodes[i + 1].skip] = k;
+            }
+            key[0] = 1e300;                             // the root is visited by every walk
+            std::nth_element(pick.begin(), pick.begin() + kMaxLdsNodes, pick.end(), [&](int32_t x, int32_t y) {
+                return key[(size_t)x] > key[(size_t)y] || (key[(size_t)x] == key[(size_t)y] && x < y);
+            });
+            for (int32_t q = 0; q < kMaxLdsNodes; q++) in_prefix[pick[(size_t)q]] = 1;
+        }
+        int32_t next_slot = 0;
+        for (int32_t q = 0; q < n_nodes; q++)           // the staged ones, breadth-first among themselves
+            if (in_prefix[order[q]]) slot[order[q]] = next_slot++;
         for (int32_t i : walk)
             if (!in_prefix[i]) slot[i] = next_slot++;
     }

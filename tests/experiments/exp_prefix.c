@@ -53,5 +53,25 @@ int main(void)
     int marks[] = {256, 512, 1024, 2048, 3072, 4096, 8192};
     int m = 0;
     for (int i = 0; i < g_n && m < 7; i++) { acc += g_hits[i]; if (i + 1 == marks[m]) { printf("first %5d nodes breadth-first: %.1f %% of the visits\n", marks[m], 100.0 * acc / total); m++; } }
+    /* the same number of nodes chosen by the surface area of the box whose test admits the walk to the node
+     * (its parent's; the root's own for the root), weighted or not by the inverse distance to the eye */
+    static double key[MAXN]; static int parent[MAXN]; static int order[MAXN];
+    parent[0] = 0;
+    for (int i = 0, q = 1; i < g_n; i++) if (!g_nodes[i]->is_leaf) { parent[q++] = i; parent[q++] = i; }
+    for (int mode = 0; mode < 3; mode++) {
+        for (int i = 0; i < g_n; i++) {
+            const bvh_node *pn = g_nodes[parent[i]];
+            v3 e = vsub(pn->bmax, pn->bmin);
+            double sa = 2.0 * ((double)e.x * e.y + (double)e.y * e.z + (double)e.z * e.x);
+            v3 c = vmul(vadd(pn->bmin, pn->bmax), vfill(0.5f));
+            double dx = c.x - eye[0], dy = c.y - eye[1], dz = c.z - eye[2], d2 = dx * dx + dy * dy + dz * dz + 1.0;
+            key[i] = mode == 0 ? sa : (mode == 1 ? sa / sqrt(d2) : sa / d2);
+            order[i] = i;
+        }
+        /* selection by repeated partial sort is fine at this size */
+        for (int i = 0; i < g_n; i++) for (int j = i + 1; j < g_n && i < 4096; j++) if (key[order[j]] > key[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        acc = 0; m = 0;
+        for (int i = 0; i < 4096 && m < 6; i++) { acc += g_hits[order[i]]; if (i + 1 == marks[m]) { printf("mode %d, the %5d nodes of largest key: %.1f %% of the visits\n", mode, marks[m], 100.0 * acc / total); m++; } }
+    }
     return 0;
 }
