@@ -9,7 +9,7 @@ same scene, camera and seed.  Bars (BASELINE.json north_star / SURVEY.md section
 import numpy as np
 import pytest
 
-from conftest import RENDER_SEED, make_raytracer
+from conftest import MAIN_RS_CAMERA, RENDER_SEED, make_raytracer
 
 pytestmark = pytest.mark.gpu
 
@@ -290,9 +290,9 @@ def test_library_built_bvh_equals_host_built(renderer):
 
 
 def test_big_scene_beyond_lds_prefix(renderer, oracle):
-    """~10.7k spheres: only the top 1024 nodes sit in LDS, the rest come through the L1."""
+    """~10.7k spheres: 2048 of the 21k nodes sit in LDS, the rest come through the L1."""
     rt = make_raytracer("reference", 120, 68, 2)
-    assert len(rt.nodes) > 1024
+    assert len(rt.nodes) > 2048
     osc = oracle.OracleScene(rt.packed)
     ref = osc.render(rt.camera.pod, 2, seed=RENDER_SEED, hit_ids=True)
     renderer.set_lanes_per_pixel(1)
@@ -301,6 +301,28 @@ def test_big_scene_beyond_lds_prefix(renderer, oracle):
     finally:
         renderer.set_lanes_per_pixel(0)
     assert np.array_equal(ids, ref["hit_id"]) and same_bits(rad, ref["radiance"])
+
+
+def test_tree_that_fills_the_staged_set(renderer, oracle):
+    """~800 spheres, 1024 < nodes <= 2048: the whole tree is staged, both halves -- more than the 48 KiB of dynamic
+    LDS a kernel gets without asking (launch_path raises the cap) -- in both walk orders."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    pt.random_scene(scene, 7, (-11, 11, -11, 26))
+    cam = pt.Camera.new(width=120, height=68, **MAIN_RS_CAMERA)
+    rt = pt.Raytracer.new(cam, scene, 3)
+    assert 1024 < len(rt.nodes) <= 2048
+    osc = oracle.OracleScene(rt.packed)
+    ref = osc.render(rt.camera.pod, 3, seed=RENDER_SEED, hit_ids=True)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        for view in (True, False):
+            renderer.set_walk_order(view)
+            _, rad, ids = renderer.render(rt, seed=RENDER_SEED, radiance=True, hit_ids=True)
+            assert np.array_equal(ids, ref["hit_id"]) and same_bits(rad, ref["radiance"])
+    finally:
+        renderer.set_walk_order(True)
+        renderer.set_lanes_per_pixel(0)
 
 
 def test_accumulate_continues_the_sequential_sum(renderer, oracle):
