@@ -206,6 +206,35 @@ def test_second_stream_while_a_launch_is_running_is_refused(renderer, oracle):
     assert same_bits(buf_a.cpu().numpy(), buf_b.cpu().numpy())
 
 
+def test_two_contexts_render_on_one_gpu_at_once(renderer, oracle):
+    """Two contexts, two streams, launches in flight together: each launch is sized to fill the GPU by itself
+    (persistent) and waits only for items its own running waves hold, so the second one takes the slots the
+    first one frees -- both frames come out as when rendered alone."""
+    import path_tracer_amd as pt
+    torch = pytest.importorskip("torch")
+    rt_a = make_raytracer("rtow", 960, 540, 12)
+    rt_b = make_raytracer("reference", 640, 360, 6)
+    other = pt.ParallelRenderer.new(0)
+    try:
+        dev = torch.device("cuda", 0)
+        sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        buf_a = torch.zeros(rt_a.width() * rt_a.height() * 3, dtype=torch.float32, device=dev)
+        buf_b = torch.zeros(rt_b.width() * rt_b.height() * 3, dtype=torch.float32, device=dev)
+        renderer.bind(rt_a)
+        other.bind(rt_b)
+        torch.cuda.synchronize()
+        renderer.render_device(rt_a, buf_a.data_ptr(), seed=5, stream=sa.cuda_stream)
+        other.render_device(rt_b, buf_b.data_ptr(), seed=6, stream=sb.cuda_stream)
+        sa.synchronize()
+        sb.synchronize()
+        alone_a = renderer.render(rt_a, seed=5, radiance=True)[1]
+        alone_b = other.render(rt_b, seed=6, radiance=True)[1]
+        assert same_bits(buf_a.cpu().numpy().reshape(alone_a.shape), alone_a)
+        assert same_bits(buf_b.cpu().numpy().reshape(alone_b.shape), alone_b)
+    finally:
+        other.close()
+
+
 def test_axis_aligned_rays_nan_and_inf_slabs(renderer, oracle):
     """Camera looking straight down -z with eye.x = eye.y = 0: the centre column / row of
     pixels get direction components that are EXACTLY zero (1/0 = inf), and spheres are placed
