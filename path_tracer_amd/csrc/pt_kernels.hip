@@ -73,6 +73,9 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
                               // pieces run one after another): 32 -> 64 is -12 % on cfg 2 (256 spp: 4 pieces instead of 8),
                               // -1.8 % at 529 spp (one GPU's share of the headline frame on 8), nothing at 1024 and 4096 spp
 #endif
+#ifndef PT_SPLIT_UNROLL
+#define PT_SPLIT_UNROLL 1   // two node visits per trip of the SPLIT run (split_run_regular)
+#endif
 #ifndef PT_ITEMS_PER_SLOT
 #define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
 #endif
@@ -175,16 +178,35 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
     PT_RUN_CHAINS \
     "v_cmp_lt_f32 vcc, " RE ", " RF "\n s_nop 1\n" \
     "v_cndmask_b32 %[code], " RA3 ", " RB3 ", vcc\n" \
+    PT_RUN_TAIL
+#define PT_RUN_TAIL_COUNT \
     "v_cmp_gt_u32 vcc, %[nspl], %[code]\n" \
     "s_bcnt1_i32_b64 %[cnt], vcc\n s_cmp_ge_i32 %[cnt], %[keep]\n s_cselect_b64 exec, vcc, 0\n"
+#define PT_RUN_TAIL PT_RUN_TAIL_COUNT
     if (ALL_IN_LDS) {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUN%=:\n"
+#if PT_SPLIT_UNROLL
+// Two visits per trip: the first leaves through exec alone (v_cmpx: the lanes still on a Split), only the second
+// counts them against `keep` -- three scalar instructions fewer per two visits, and a run may go one visit past the
+// count that would have ended it, with the lanes that are still in it: -0.4 to -1.0 % in four A/B runs (three or four
+// visits per trip: no more).
+#undef PT_RUN_TAIL
+#define PT_RUN_TAIL "v_cmpx_gt_u32 vcc, %[nspl], %[code]\n"
+                     "ds_read_b128 " RA ", %[code]\n"
+                     "ds_read_b128 " RB ", %[code] offset:%[n1off]\n"
+                     "s_waitcnt lgkmcnt(1)\n"
+                     PT_RUN_TEST
+                     "s_cbranch_execz .LPTRUNX%=\n"
+#undef PT_RUN_TAIL
+#define PT_RUN_TAIL PT_RUN_TAIL_COUNT
+#endif
                      "ds_read_b128 " RA ", %[code]\n"
                      "ds_read_b128 " RB ", %[code] offset:%[n1off]\n"
                      "s_waitcnt lgkmcnt(1)\n"
                      PT_RUN_TEST
                      "s_cbranch_execnz .LPTRUN%=\n"
+                     ".LPTRUNX%=:\n"
                      "s_mov_b64 exec, %[save]\n"
                      : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
                      : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
@@ -239,16 +261,27 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
     "v_med3_f32 v56, v56, v50, v54\n v_med3_f32 v57, v57, v50, v54\n" \
     "v_cmp_lt_f32 vcc, v56, v57\n s_nop 1\n" \
     "v_cndmask_b32 %[code], v51, v55, vcc\n" \
-    "v_cmp_gt_u32 vcc, %[nspl], %[code]\n" \
-    "s_bcnt1_i32_b64 %[cnt], vcc\n s_cmp_ge_i32 %[cnt], %[keep]\n s_cselect_b64 exec, vcc, 0\n"
+    PT_RUN_TAIL
     if (ALL_IN_LDS) {
         asm volatile("s_mov_b64 %[save], exec\n"
                      ".LPTRUNF%=:\n"
+#if PT_SPLIT_UNROLL   // two visits per trip, as in split_run_regular
+#undef PT_RUN_TAIL
+#define PT_RUN_TAIL "v_cmpx_gt_u32 vcc, %[nspl], %[code]\n"
+                     "ds_read_b128 v[48:51], %[code]\n"
+                     "ds_read_b128 v[52:55], %[code] offset:%[n1off]\n"
+                     "s_waitcnt lgkmcnt(1)\n"
+                     PT_RUN_TEST_FAST
+                     "s_cbranch_execz .LPTRUNFX%=\n"
+#undef PT_RUN_TAIL
+#define PT_RUN_TAIL PT_RUN_TAIL_COUNT
+#endif
                      "ds_read_b128 v[48:51], %[code]\n"
                      "ds_read_b128 v[52:55], %[code] offset:%[n1off]\n"
                      "s_waitcnt lgkmcnt(1)\n"
                      PT_RUN_TEST_FAST
                      "s_cbranch_execnz .LPTRUNF%=\n"
+                     ".LPTRUNFX%=:\n"
                      "s_mov_b64 exec, %[save]\n"
                      : [code] "+v"(code), [save] "=&s"(save), [cnt] "=&s"(cnt)
                      : [nx] "v"(noi.x), [ny] "v"(noi.y), [nz] "v"(noi.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
