@@ -112,3 +112,62 @@ def _sphere_scene(pt):
     sc = pt.Scene.new()
     sc.add(pt.Sphere.new((0, 0, 0), 1.0, pt.Lambertian.new_solid((0.5, 0.5, 0.5))))
     return sc
+
+
+def _ext_fuzz_material(rnd):
+    import path_tracer_amd as pt
+    m = int(rnd.integers(0, 5))
+    if m <= 1:
+        return pt.Lambertian.new_solid(tuple(float(x) for x in rnd.uniform(0.05, 0.95, 3)))
+    if m == 2:
+        return pt.Metal.new(tuple(float(x) for x in rnd.uniform(0.3, 1.0, 3)), float(rnd.choice([0.0, 0.3, 1.0])))
+    if m == 3:
+        return pt.Dielectric.new(float(rnd.choice([1.5, 0.7, 2.4])))
+    return pt.DiffuseLight.new(tuple(float(x) for x in rnd.uniform(0.5, 8.0, 3)))
+
+
+def _ext_fuzz_case(k):
+    """Seeded random extension scene + camera + integrator (tools/ext_fuzz_campaign.py runs 300,000 of them)."""
+    import path_tracer_amd as pt
+    rnd = np.random.default_rng(500000 + k)
+    sc = pt.Scene.new()
+    n_rects = int(rnd.choice([1, 2, 4, 8, 14]))
+    for _ in range(n_rects):
+        axis = int(rnd.integers(0, 3))
+        a0, b0 = (float(x) for x in rnd.uniform(-3.0, 2.0, 2))
+        a1, b1 = a0 + float(rnd.uniform(0.2, 4.0)), b0 + float(rnd.uniform(0.2, 4.0))
+        sc.add(pt.Rect(axis, a0, a1, b0, b1, float(rnd.uniform(-3.0, 3.0)), _ext_fuzz_material(rnd), flip=bool(rnd.integers(0, 2))))
+    for _ in range(int(rnd.choice([0, 1, 2, 3]))):
+        tr = pt.Transform.new(tuple(float(x) for x in rnd.uniform(-2.5, 2.5, 3)), float(rnd.choice([0.0, 15.0, -18.0, 45.0, 90.0, 133.0, -270.0])))
+        size = tuple(float(x) for x in rnd.uniform(0.3, 2.0, 3))
+        for r in pt.box_rects((0.0, 0.0, 0.0), size, _ext_fuzz_material(rnd), tr if rnd.integers(0, 4) else None):
+            sc.add(r)
+    for _ in range(int(rnd.choice([0, 1, 3, 9]))):
+        sc.add(pt.Sphere.new(tuple(float(x) for x in rnd.uniform(-3.0, 3.0, 3)), float(rnd.choice([0.1, 0.5, 1.5, 30.0], p=[0.3, 0.4, 0.25, 0.05])),
+                             _ext_fuzz_material(rnd)))
+    eye = rnd.uniform(-5.0, 5.0, 3)
+    target = rnd.uniform(-1.0, 1.0, 3)
+    if k % 7 == 0:                                          # axis-aligned view: zero direction components
+        eye, target = np.array([0.0, 0.0, 6.0]), np.array([0.0, 0.0, 0.0])
+    fov = float(rnd.choice([10.0, 40.0, 90.0, 150.0]))
+    w, h = [(33, 17), (64, 36), (48, 48), (24, 64)][k % 4]
+    cam = pt.Camera.new(tuple(map(float, eye)), tuple(map(float, target)), (0.0, 1.0, 0.0), fov, w, h)
+    kind = k % 4
+    if kind == 0:
+        integ = None
+    elif kind == 1:
+        integ = pt.Integrator(max_bounces=int(rnd.choice([1, 3, 12, 50])), background=tuple(float(x) for x in rnd.uniform(0.0, 0.5, 3)))
+    elif kind == 2:
+        integ = pt.Integrator(max_bounces=int(rnd.choice([4, 20])), rr_start=int(rnd.choice([0, 2, 5])))
+    else:
+        integ = pt.Integrator(max_bounces=50, background=(0.0, 0.0, 0.0), rr_start=int(rnd.choice([-1, 3])))
+    samples = int(rnd.choice([2, 3, 5]))
+    return pt.Raytracer.new(cam, sc, samples, integrator=integ), samples
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_extension_fuzz_scenes_bit_exact(renderer, oracle, k):
+    """random rects / instanced boxes / spheres / lights / integrator options / cameras, both lane modes"""
+    rt, s = _ext_fuzz_case(k)
+    check(renderer, oracle, rt, s, 1, seed=k)
+    check(renderer, oracle, rt, s, 0, seed=k)

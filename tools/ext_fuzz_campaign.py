@@ -21,52 +21,7 @@ import oracle_lib  # noqa: E402   (the checker)
 import path_tracer_amd as pt  # noqa: E402
 
 
-def material(rnd):
-    m = int(rnd.integers(0, 5))
-    if m <= 1:
-        return pt.Lambertian.new_solid(tuple(float(x) for x in rnd.uniform(0.05, 0.95, 3)))
-    if m == 2:
-        return pt.Metal.new(tuple(float(x) for x in rnd.uniform(0.3, 1.0, 3)), float(rnd.choice([0.0, 0.3, 1.0])))
-    if m == 3:
-        return pt.Dielectric.new(float(rnd.choice([1.5, 0.7, 2.4])))
-    return pt.DiffuseLight.new(tuple(float(x) for x in rnd.uniform(0.5, 8.0, 3)))
-
-
-def ext_case(k):
-    rnd = np.random.default_rng(500000 + k)
-    sc = pt.Scene.new()
-    n_rects = int(rnd.choice([1, 2, 4, 8, 14]))
-    for _ in range(n_rects):
-        axis = int(rnd.integers(0, 3))
-        a0, b0 = (float(x) for x in rnd.uniform(-3.0, 2.0, 2))
-        a1, b1 = a0 + float(rnd.uniform(0.2, 4.0)), b0 + float(rnd.uniform(0.2, 4.0))
-        sc.add(pt.Rect(axis, a0, a1, b0, b1, float(rnd.uniform(-3.0, 3.0)), material(rnd), flip=bool(rnd.integers(0, 2))))
-    for _ in range(int(rnd.choice([0, 1, 2, 3]))):
-        tr = pt.Transform.new(tuple(float(x) for x in rnd.uniform(-2.5, 2.5, 3)), float(rnd.choice([0.0, 15.0, -18.0, 45.0, 90.0, 133.0, -270.0])))
-        size = tuple(float(x) for x in rnd.uniform(0.3, 2.0, 3))
-        for r in pt.box_rects((0.0, 0.0, 0.0), size, material(rnd), tr if rnd.integers(0, 4) else None):
-            sc.add(r)
-    for _ in range(int(rnd.choice([0, 1, 3, 9]))):
-        sc.add(pt.Sphere.new(tuple(float(x) for x in rnd.uniform(-3.0, 3.0, 3)), float(rnd.choice([0.1, 0.5, 1.5, 30.0], p=[0.3, 0.4, 0.25, 0.05])),
-                             material(rnd)))
-    eye = rnd.uniform(-5.0, 5.0, 3)
-    target = rnd.uniform(-1.0, 1.0, 3)
-    if k % 7 == 0:                                          # axis-aligned view: zero direction components
-        eye, target = np.array([0.0, 0.0, 6.0]), np.array([0.0, 0.0, 0.0])
-    fov = float(rnd.choice([10.0, 40.0, 90.0, 150.0]))
-    w, h = [(33, 17), (64, 36), (48, 48), (24, 64)][k % 4]
-    cam = pt.Camera.new(tuple(map(float, eye)), tuple(map(float, target)), (0.0, 1.0, 0.0), fov, w, h)
-    kind = k % 4
-    if kind == 0:
-        integ = None
-    elif kind == 1:
-        integ = pt.Integrator(max_bounces=int(rnd.choice([1, 3, 12, 50])), background=tuple(float(x) for x in rnd.uniform(0.0, 0.5, 3)))
-    elif kind == 2:
-        integ = pt.Integrator(max_bounces=int(rnd.choice([4, 20])), rr_start=int(rnd.choice([0, 2, 5])))
-    else:
-        integ = pt.Integrator(max_bounces=50, background=(0.0, 0.0, 0.0), rr_start=int(rnd.choice([-1, 3])))
-    samples = int(rnd.choice([2, 3, 5]))
-    return pt.Raytracer.new(cam, sc, samples, integrator=integ), samples
+from test_gpu_ext import _ext_fuzz_case as ext_case  # noqa: E402
 
 
 def main():
