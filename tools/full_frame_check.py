@@ -42,6 +42,8 @@ def heartbeat():
 
 
 osc = oracle_lib.OracleScene(rt.packed)
+if getattr(rt, "integrator", None) is not None:      # extension scenes (cfg 4): bounce cap, background, roulette
+    osc.set_integrator(rt.integrator.pod)
 t1 = time.time()
 threading.Thread(target=heartbeat, daemon=True).start()
 ref = osc.render(rt.camera.pod, samples, seed=bench.RENDER_SEED, hit_ids=True, threads=16)
