@@ -44,8 +44,11 @@ typedef enum {
 
 /* Sphere {center, radius, material}: src/traceable/sphere.rs:20-24.  `material`
  * indexes the materials array (shared Arc<dyn Material>s de-duplicated by the
- * host).  Primitive id = index in this array = Scene::add order
- * (src/scene/mod.rs:46-48). */
+ * host).  Primitive id (hit-id AOV) = the caller's index in this array, whatever
+ * order the caller filled it in: Scene::add order (src/scene/mod.rs:46-48) for a
+ * host that packs Scene::objects before construct_bvh drains it (the C++ and Python
+ * hosts here), leaf order of the built tree for the Rust packer, which can only walk
+ * the BvhNode tree afterwards (integration/rust/src/gpu.rs flatten). */
 typedef struct {
     float cx, cy, cz, radius;
     int32_t material;
@@ -161,8 +164,17 @@ int pt_primary_hits_device(pt_context *ctx, int32_t samples, int32_t sample_inde
  *   limit : frames of at most 262,144 8x8 tiles (16.7 M pixels; 3840x2160 has 129,600); larger
  *           frames return PT_ERR_LIMIT.
  *   sharing: ALL contexts on one GPU share that GPU's array (it is cleared at the start of every
- *           launch), so launches of this entry point that overlap in time on one GPU -- from
- *           different streams or different contexts -- race.  Issue them on one stream at a time. */
+ *           launch), so two launches of this entry point must not overlap in time on one GPU.  The
+ *           library keeps the array's in-flight record per GPU: a launch on another stream -- of
+ *           this context or of any other context of the GPU -- while the array's previous launch has
+ *           not completed returns PT_ERR_INVALID instead of racing (launches on ONE stream are
+ *           ordered and fine).  GPUs beyond the 64th of a process are not tracked.
+ *   capture: on a stream under HIP graph capture the call records a memset node and a kernel node and
+ *           nothing else (no events, no in-flight check: ordering is the graph's business; the occupancy
+ *           and attribute queries of the launch are cached from the first un-captured launch of the same
+ *           scene size).  pt_last_path_kernel_ms returns -1 for such a launch.  tests/test_zz_no_alloc.py
+ *           captures pt_render_device_static + pt_resolve_device, replays the graph twice and compares
+ *           with pt_render bit for bit. */
 int pt_render_device_static(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
                             int32_t sample_end, int32_t accumulate, float *d_radiance, void *stream);
 
@@ -188,10 +200,14 @@ float pt_last_path_kernel_ms(pt_context *ctx);
  *   PT_EXACT (default): every + - * / sqrt is one correctly rounded fp32 operation in the reference's
  *            order, nothing fused (Rust never contracts a * b + c): radiance equals the oracle's bit for bit.
  *   PT_FAST : opt-in.  Fused multiply-adds, hardware reciprocal / square-root estimates, the slab test
- *            with one fma per plane.  Within BASELINE's tolerance of the EXACT result (>= 99.9 % of
- *            pixels within 1/255 after tonemapping at equal spp and seed, converged RMSE < 1e-3), not
- *            bit-equal to it.  Applies to pt_upload_scene scenes; the hit-id AOV, the resolve and the
- *            extension's scenes (pt_upload_scene_ext) always run EXACT. */
+ *            with one fma per plane.  Not bit-equal to the EXACT result; within BASELINE's tolerance of
+ *            it (>= 99.9 % of pixels within 1/255 after tonemapping at equal spp and seed, converged
+ *            RMSE < 1e-3) on the 256-, 1024- and 4096-spp configurations (99.94 - 99.99 % measured).
+ *            EXCEPTION: at 100 spp (BASELINE config 1, 400x225) it measures 99.78 %, BELOW the 99.9 %
+ *            bar -- one path that takes another way moves a pixel by more than 1/255 at so few samples --
+ *            so PT_FAST does not meet the north-star tolerance there (tests/test_gpu_fast.py holds it to
+ *            99.5 % for that frame and says so).  Applies to pt_upload_scene scenes; the hit-id AOV, the
+ *            resolve and the extension's scenes (pt_upload_scene_ext) always run EXACT. */
 enum { PT_EXACT = 0, PT_FAST = 1 };
 int pt_set_mode(pt_context *ctx, int32_t mode);
 
@@ -220,6 +236,14 @@ int pt_set_mode(pt_context *ctx, int32_t mode);
 enum { PT_WALK_REFERENCE = 0, PT_WALK_VIEW = 1 };
 int pt_set_walk_order(pt_context *ctx, int32_t order);
 int pt_get_walk_order(const pt_context *ctx);   /* the order in effect for the uploaded scene */
+
+/* The shader clock of the context's GPU right now, in GHz: a two-millisecond chip-filling chain of fp32
+ * multiplies (its own small kernel, 8 waves per SIMD like the path kernel) stamped with the shader-cycle
+ * counter and the constant 100 MHz counter; the median over its workgroups of cycles per tick.  No
+ * counterpart in the reference.  For measurement records: a frame's time is cycles / clock, and the
+ * clock is the chip's choice under load -- bench.py calls this right before and right after its timed
+ * region so that a slower box can be told from a slower kernel.  Blocking; allocates. */
+int pt_clock_probe(pt_context *ctx, float *ghz);
 
 /* How a pixel's samples are spread over GPU lanes.  0 (default) = automatic:
  * one lane owns all samples of a pixel whenever the frame alone fills the GPU,
@@ -344,7 +368,25 @@ int pt_group_set_integrator(pt_group *group, const pt_integrator *integrator);
 /* pt_render of the full grid over the group.  Blocking.  rgb8 / radiance: host buffers as for
  * pt_render (either may be NULL); radiance is the merged sum. */
 int pt_group_render(pt_group *group, int32_t samples, uint64_t seed, uint8_t *rgb8, float *radiance);
-/* Share of GPU `rank` of n: sample indices [*begin, *end), contiguous, sizes differ by at most one. */
+/* pt_group_render waits for the GPUs with a bounded poll (hipStreamQuery + ncclCommGetAsyncError per GPU), not
+ * a blind hipStreamSynchronize: a GPU that reports an error, or has not finished within the group's timeout,
+ * comes back as PT_ERR_HIP with that GPU named in pt_group_last_error; every communicator is then aborted
+ * (ncclCommAbort, which releases the reduce kernels of the GPUs that did join) and the group refuses further
+ * renders -- destroy it and create a new one.  Default timeout 600,000 ms; 0 = no limit.  pt_group_destroy on
+ * an aborted group does not wait for a GPU whose stream never drains (that GPU's buffers are leaked instead).
+ * NOTE: the n >= 2 path has been exercised by host-side fault injection and on CPU (gloo) only; no execution
+ * on two or more GPUs exists yet (the build box has one). */
+int pt_group_set_timeout(pt_group *group, int32_t milliseconds);
+/* NCCL_VERSION_CODE the library was compiled against and what ncclGetVersion of the RCCL the process actually
+ * loaded reports (under Python that is torch's bundled librccl.so, for a C++ / Rust host /opt/rocm/lib's).
+ * pt_group_create refuses a loaded library of another MAJOR version (PT_ERR_HIP, both numbers in the message). */
+int pt_group_rccl_version(const pt_group *group, int32_t *compiled, int32_t *loaded);
+/* TEST HOOK, host side only (nothing is provoked on a GPU): the next pt_group_render's wait treats GPU `rank` as
+ * reporting an asynchronous RCCL error (kind 1) or as never finishing (kind 2, until the timeout); kind 0 clears.
+ * Exercises the error path of the bounded wait on a one-GPU box. */
+int pt_group_inject_fault(pt_group *group, int32_t rank, int32_t kind);
+/* Share of GPU `rank` of n: sample indices [*begin, *end), contiguous, sizes differ by at most one.  n < 1 or a
+ * rank outside [0, n): the empty range [0, 0). */
 void pt_group_shard(int32_t samples, int32_t rank, int32_t n, int32_t *begin, int32_t *end);
 /* Timings of the last pt_group_render: kernel_ms[r] = GPU r's path kernel (HIP events on its stream),
  * up to `capacity` entries; *reduce_ms = from the end of the root's path kernel to the end of the

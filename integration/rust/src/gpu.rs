@@ -108,6 +108,7 @@ extern "C" {
     pub fn pt_set_mode(ctx: *mut pt_context, mode: i32) -> c_int;
     pub fn pt_set_walk_order(ctx: *mut pt_context, order: i32) -> c_int;
     pub fn pt_get_walk_order(ctx: *const pt_context) -> c_int;
+    pub fn pt_clock_probe(ctx: *mut pt_context, ghz: *mut f32) -> c_int;
     pub fn pt_set_lanes_per_pixel(ctx: *mut pt_context, lanes: i32) -> c_int;
     pub fn pt_get_lanes_per_pixel(ctx: *const pt_context, samples: i32, sample_begin: i32, sample_end: i32) -> c_int;
     // start-up checks: each must report 0 mismatches
@@ -143,6 +144,9 @@ extern "C" {
                                      nodes: *const pt_bvh_node, n_nodes: i32) -> c_int;
     pub fn pt_group_set_integrator(group: *mut pt_group, integrator: *const pt_integrator) -> c_int;
     pub fn pt_group_render(group: *mut pt_group, samples: i32, seed: u64, rgb8: *mut u8, radiance: *mut f32) -> c_int;
+    pub fn pt_group_set_timeout(group: *mut pt_group, milliseconds: i32) -> c_int;
+    pub fn pt_group_rccl_version(group: *const pt_group, compiled: *mut i32, loaded: *mut i32) -> c_int;
+    pub fn pt_group_inject_fault(group: *mut pt_group, rank: i32, kind: i32) -> c_int;
     pub fn pt_group_shard(samples: i32, rank: i32, n: i32, begin: *mut i32, end: *mut i32);
     pub fn pt_group_timings(group: *const pt_group, kernel_ms: *mut f32, capacity: i32, reduce_ms: *mut f32) -> c_int;
     // host-side helpers (pure CPU)

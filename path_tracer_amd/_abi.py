@@ -86,6 +86,7 @@ SIGNATURES = {
     "pt_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_set_walk_order": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_walk_order": (C.c_int, [C.c_void_p]),
+    "pt_clock_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pt_set_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_selftest_unary": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
@@ -112,6 +113,9 @@ SIGNATURES = {
                                         C.POINTER(PtTexture), C.c_int32, C.POINTER(PtBvhNode), C.c_int32]),
     "pt_group_set_camera": (C.c_int, [C.c_void_p, C.POINTER(PtCamera)]),
     "pt_group_render": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pt_group_set_timeout": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pt_group_rccl_version": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pt_group_inject_fault": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pt_group_shard": (None, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pt_group_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
     "pt_bvh_build": (C.c_int32, [C.POINTER(PtSphere), C.c_int32, C.POINTER(PtBvhNode), C.c_int32]),

@@ -321,9 +321,17 @@ int thread_nodes(pt_context *c)
         h_n0[slot[i]] = a;
         h_n1[slot[i]] = b;
     }
-    PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, hipDeviceSynchronize());   // launches on caller streams (pt_render_device) may still be walking the old arrays
-    PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    // A camera whose eye orders every Split's children -- and picks the staged set -- as the previous one did
+    // threads the tree into the same arrays: then the device copy stays as it is (no device-wide wait, no copy).
+    const bool same = c->threaded && c->h_threaded.size() == h_nodes.size() &&
+                      std::memcmp(c->h_threaded.data(), h_nodes.data(), h_nodes.size() * sizeof(float4)) == 0;
+    if (!same) {
+        PT_HIP(c, hipSetDevice(c->device));
+        PT_HIP(c, hipDeviceSynchronize());   // launches on caller streams (pt_render_device) may still be walking the old arrays
+        c->threaded = false;                 // until the copy has succeeded the device arrays are in no known state
+        PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+        c->h_threaded.swap(h_nodes);
+    }
     c->scene.root_code = code_of(0);
     c->threaded = true;
     c->threaded_view = view;
@@ -372,11 +380,14 @@ int pt_create(int32_t device, pt_context **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_own_done, hipEventDisableTiming);
     // each GPU holds its own copy of the scratch array at its own address: resolved here, with this
     // context's device current, and used through this pointer only
     if (e == hipSuccess) e = ptk::static_sched(device, &c->static_sched, &c->static_sched_bytes);
     if (e != hipSuccess) {
         if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+        if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+        if (c->ev_own_done) (void)hipEventDestroy(c->ev_own_done);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return fail(nullptr, PT_ERR_HIP, "device binding / stream / event creation failed: %s", hipGetErrorString(e));
@@ -395,6 +406,7 @@ void pt_destroy(pt_context *c)
     if (c->d_sched) (void)hipFree(c->d_sched);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_own_done) (void)hipEventDestroy(c->ev_own_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -615,6 +627,7 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     c->h_tree.swap(h_tree);
     c->h_leaf.swap(h_leaf);
     c->threaded = false;
+    c->h_threaded.clear();
     const int rc = thread_nodes(c);
     if (rc != PT_OK) return rc;
     c->have_scene = true;
@@ -712,13 +725,25 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
             return fail(c, PT_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e));
         }
         if (c->last_sched == c->d_sched) c->last_sched = nullptr;
+        c->own_used = false;                       // the device is idle: nothing is in flight on the old scratch
         if (c->d_sched) (void)hipFree(c->d_sched);
         c->d_sched = fresh;
         c->sched_bytes = need;
     }
+    // PT_WALK_VIEW orders the walk by the camera's origin: thread the nodes for the new eye first; if that fails
+    // the context keeps its previous camera (and the message of the failure)
+    const ptd::Camera previous = c->camera;
+    const bool had_camera = c->have_camera;
     c->camera = next;
     c->have_camera = true;
-    if (c->have_scene) return thread_nodes(c);   // PT_WALK_VIEW orders the walk by the camera's origin
+    if (c->have_scene) {
+        const int rc = thread_nodes(c);
+        if (rc != PT_OK) {
+            c->camera = previous;
+            c->have_camera = had_camera;
+            return rc;
+        }
+    }
     return PT_OK;
 }
 
@@ -774,6 +799,45 @@ int pt_selftest_grid(pt_context *c, int32_t samples, uint64_t *mismatches)
     (void)hipFree(d_count);
     if (e != hipSuccess) return fail(c, PT_ERR_HIP, "pt_selftest_grid failed: %s", hipGetErrorString(e));
     *mismatches = h_count;
+    return PT_OK;
+}
+
+int pt_clock_probe(pt_context *c, float *ghz)
+{
+    if (!c || !ghz) return PT_ERR_INVALID;
+    *ghz = 0.0f;
+    PT_HIP(c, hipSetDevice(c->device));
+    int cus = 0;
+    PT_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int groups = cus * 8;            // 8 groups of 4 waves per CU: 8 waves per SIMD, the path kernel's occupancy
+    const int iters = 1800;                // x 128 multiplies per wave: about 2 ms at 2.2 GHz
+    std::vector<unsigned long long> h;
+    try {
+        h.assign(2 * (size_t)groups, 0ull);
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
+    }
+    unsigned long long *d_stamps = nullptr;
+    float *d_sink = nullptr;
+    PT_HIP(c, hipMalloc((void **)&d_stamps, h.size() * sizeof(unsigned long long) + 256));
+    d_sink = (float *)(d_stamps + h.size());
+    hipError_t e = ptk::launch_clock_probe(d_stamps, d_sink, groups, iters, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_stamps);
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, "pt_clock_probe failed: %s", hipGetErrorString(e));
+    // median over the groups of cycles per 100 MHz tick
+    std::vector<double> ratio;
+    try {
+        ratio.reserve((size_t)groups);
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "out of host memory");
+    }
+    for (int i = 0; i < groups; i++)
+        if (h[2 * (size_t)i + 1] > 0) ratio.push_back((double)h[2 * (size_t)i] / (double)h[2 * (size_t)i + 1]);   // within the reservation
+    if (ratio.empty()) return fail(c, PT_ERR_HIP, "pt_clock_probe: no group reported a stamp");
+    std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
+    *ghz = (float)(ratio[ratio.size() / 2] * 0.1);
     return PT_OK;
 }
 
@@ -851,18 +915,43 @@ static int render_device_with(pt_context *c, int32_t samples, uint64_t seed, int
     (void)hipMemsetAsync(d_stats, 0, 128, st);
     rp.stats = d_stats;
 #endif
+    // A stream under HIP graph capture records the memset and the kernel launch and nothing else: no events (a
+    // captured event cannot be queried or timed afterwards) and no in-flight check (ordering is the graph's).
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    const bool capturing = capture == hipStreamCaptureStatusActive;
+    const bool is_static = sched == c->static_sched;
     // One launch at a time per scratch: launches on one stream are ordered; a launch on ANOTHER stream
-    // while the previous one is still in flight would clear the tickets under it -- refused, not raced.
-    if (c->timed && c->last_sched == sched && c->last_stream != st && hipEventQuery(c->ev_stop) == hipErrorNotReady)
-        return fail(c, PT_ERR_INVALID, "the previous path-kernel launch of this context is still running on another stream: "
-                                       "its launches share one work-distribution scratch (one stream at a time)");
-    PT_HIP(c, hipEventRecord(c->ev_start, st));
+    // while the previous one is still in flight would clear the tickets under it -- refused, not raced.  The
+    // context's own scratch is guarded by the context's record, the library's static array (shared by every
+    // context of the GPU) by the array's own record in pt_kernels.hip.
+    if (!capturing) {
+        if (!is_static && c->own_used && c->own_stream != st && hipEventQuery(c->ev_own_done) == hipErrorNotReady)
+            return fail(c, PT_ERR_INVALID, "the previous path-kernel launch of this context is still running on another stream: "
+                                           "its launches share one work-distribution scratch (one stream at a time)");
+        if (is_static) {
+            bool busy = false;
+            PT_HIP(c, ptk::static_claim(c->device, st, &busy));
+            if (busy)
+                return fail(c, PT_ERR_INVALID, "the library's static scratch array on device %d is still in use by a launch on another "
+                                               "stream (pt_render_device_static: all contexts of a GPU share it, one stream at a time)", c->device);
+        }
+        PT_HIP(c, hipEventRecord(c->ev_start, st));
+    }
     c->last_sched = sched;
     c->last_stream = st;
     if (c->mode == PT_FAST && !c->scene.ext) PT_HIP(c, ptk_fast::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
     else PT_HIP(c, ptk::launch_path(c->scene, c->camera, rp, sched, d_radiance, st));
-    PT_HIP(c, hipEventRecord(c->ev_stop, st));
-    c->timed = true;
+    if (!capturing) {
+        PT_HIP(c, hipEventRecord(c->ev_stop, st));
+        if (is_static) PT_HIP(c, ptk::static_mark(c->device, st));
+        else {
+            PT_HIP(c, hipEventRecord(c->ev_own_done, st));
+            c->own_stream = st;
+            c->own_used = true;
+        }
+    }
+    c->timed = !capturing;
 #ifdef PT_STATS
     {
         unsigned long long hs[16];

@@ -44,6 +44,7 @@ struct pt_context {
     // that the node arrays can be threaded again when the camera or the walk order changes (pt_api.cpp thread_nodes)
     std::vector<pt_bvh_node> h_tree;
     std::vector<float4> h_leaf;
+    std::vector<float4> h_threaded;      // host copy of what d_nodes holds (n0[] then n1[]): an unchanged threading is not uploaded again
     int32_t walk_order = PT_WALK_VIEW;   // pt_set_walk_order
     bool view_ok = false;                // not an extension scene
     bool threaded = false, threaded_view = false;   // what d_nodes holds now
@@ -56,6 +57,11 @@ struct pt_context {
     size_t static_sched_bytes = 0;
     int32_t *last_sched = nullptr;   // the scratch the most recent path-kernel launch used (its error word)
     hipStream_t last_stream = nullptr;   // and the stream it went to
+    // in-flight record of the context's OWN scratch (d_sched): an event behind its most recent launch and that
+    // launch's stream.  (The library's static array has its record in pt_kernels.hip, shared by the GPU's contexts.)
+    hipEvent_t ev_own_done = nullptr;
+    hipStream_t own_stream = nullptr;
+    bool own_used = false;
 };
 
 namespace ptapi {

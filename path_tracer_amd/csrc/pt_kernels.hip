@@ -858,6 +858,29 @@ __global__ __launch_bounds__(256) void division_selftest_kernel(unsigned long lo
     if (bad) atomicAdd(count, (unsigned long long)bad);
 }
 
+
+// pt_clock_probe: what the shader clock is RIGHT NOW.  A frame's time is cycles / clock, and the clock is the
+// chip's own choice under load (power, temperature, the box): a bench record that carries it tells a slower box
+// from a slower kernel.  Every SIMD gets 8 waves (the path kernel's occupancy) of a dependent chain of un-fused
+// fp32 multiplies for about two milliseconds; wave 0 of each group stamps s_memtime (shader cycles) and
+// s_memrealtime (a constant 100 MHz) around it, into a buffer of its own.  Not the path kernel: no stamp executes
+// in that one.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *stamps, float *sink, int iters)
+{
+    float a0 = 1.0f + (float)threadIdx.x * 1e-6f, a1 = a0 + 1e-3f, a2 = a0 + 2e-3f, a3 = a0 + 3e-3f;
+    const float m = 1.0000001f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    if (a0 + a1 + a2 + a3 == 12345.678f) sink[0] = a0;   // keeps the chain alive; never true in practice, and no output is computed from a stamp
+}
+
 #endif   // !PT_FAST_MODE
 
 // Scratch of pt_render_device_static (include/pt_amd.h): the work-distribution words of one
@@ -877,21 +900,69 @@ namespace PTK {
 
 // Device address and size of `scratch` on `device`, which must be the CURRENT device (pt_create
 // calls this right after hipSetDevice).  Resolved once per device and kept: every GPU holds its own
-// copy of the array at its own address.
+// copy of the array at its own address.  Next to the address the table keeps the array's IN-FLIGHT
+// record: all contexts of a GPU share the array, so "one launch at a time" is a property of the
+// array, not of a context (static_claim / static_mark below).
+namespace {
+constexpr int kMaxDevices = 64;
+struct StaticSlot {
+    int32_t *ptr = nullptr;
+    hipEvent_t done = nullptr;     // recorded behind the most recent launch that used the array
+    hipStream_t stream = nullptr;  // the stream that launch went to
+    bool used = false;
+};
+std::mutex g_static_lock;
+StaticSlot g_static[kMaxDevices];
+}  // namespace
+
 hipError_t static_sched(int device, int32_t **out, size_t *bytes)
 {
-    constexpr int kMaxDevices = 64;
-    static std::mutex lock;
-    static int32_t *resolved[kMaxDevices] = {};
     *bytes = sizeof(int32_t) * (size_t)kStaticSchedWords;
-    std::lock_guard<std::mutex> guard(lock);
-    if (device >= 0 && device < kMaxDevices && resolved[device]) { *out = resolved[device]; return hipSuccess; }
+    std::lock_guard<std::mutex> guard(g_static_lock);
+    if (device >= 0 && device < kMaxDevices && g_static[device].ptr) { *out = g_static[device].ptr; return hipSuccess; }
     void *p = nullptr;
     hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
-    if (device >= 0 && device < kMaxDevices) resolved[device] = (int32_t *)p;
+    if (device >= 0 && device < kMaxDevices) g_static[device].ptr = (int32_t *)p;
     *out = (int32_t *)p;
     return hipSuccess;
+}
+
+// May a launch on `stream` use the device's scratch array now?  *busy = the array's previous launch went to
+// ANOTHER stream and has not completed (launches on one stream are ordered; a launch on a second stream would
+// clear the tickets under the running kernel).  `device` must be current.  Allocates nothing after the first
+// call on a device (which creates the event).
+hipError_t static_claim(int device, hipStream_t stream, bool *busy)
+{
+    *busy = false;
+    if (device < 0 || device >= kMaxDevices) return hipSuccess;   // beyond the table: unguarded, as documented for such devices
+    std::lock_guard<std::mutex> guard(g_static_lock);
+    StaticSlot &s = g_static[device];
+    if (!s.done) {
+        const hipError_t e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e != hipSuccess) { s.done = nullptr; return e; }
+    }
+    if (s.used && s.stream != stream && hipEventQuery(s.done) == hipErrorNotReady) *busy = true;
+    return hipSuccess;
+}
+// records the launch just enqueued on `stream` as the array's most recent one
+hipError_t static_mark(int device, hipStream_t stream)
+{
+    if (device < 0 || device >= kMaxDevices) return hipSuccess;
+    std::lock_guard<std::mutex> guard(g_static_lock);
+    StaticSlot &s = g_static[device];
+    if (!s.done) return hipSuccess;
+    const hipError_t e = hipEventRecord(s.done, stream);
+    if (e != hipSuccess) return e;
+    s.stream = stream;
+    s.used = true;
+    return hipSuccess;
+}
+
+hipError_t launch_clock_probe(unsigned long long *d_stamps, float *d_sink, int groups, int iters, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)groups), dim3(256), 0, stream, d_stamps, d_sink, iters);
+    return hipGetLastError();
 }
 
 hipError_t launch_division_selftest(int log2_pairs, unsigned long long *d_count, hipStream_t stream)
@@ -990,10 +1061,6 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     const dim3 block(64 * WAVES_PER_GROUP);
     // as many workgroups as the chip holds at once; each wave draws items until none are left
     const PathArgs args{sc, cam, rp, sp, d_radiance};
-    int per_cu = 0, cus = 0, dev = 0;
-    hipError_t q = hipGetDevice(&dev);
-    if (q == hipSuccess) q = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (q != hipSuccess) return q;
     const void *fn = nullptr;
     if (!sc.ext) fn = in_lds ? (const void *)path_kernel_persistent<true, false> : (const void *)path_kernel_persistent<false, false>;
 #ifndef PT_FAST_MODE
@@ -1001,14 +1068,37 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
 #else
     else return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
 #endif
-    if (lds_bytes > 48 * 1024) {   // beyond the default cap on dynamic LDS per workgroup (a tree of more than 1023 nodes)
-        q = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (q != hipSuccess) return q;
-    }
-    q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WAVES_PER_GROUP, lds_bytes);
+    // How many groups the chip holds at once, and the LDS attribute of a launch beyond the default cap: asked once
+    // per (device, kernel, LDS size) and kept, so that a launch is a memset and a kernel launch and nothing else --
+    // which is also all a stream under HIP graph capture records.
+    struct Resident { int dev; const void *fn; size_t lds; long long groups; };
+    static std::mutex cache_lock;
+    static Resident cache[32];
+    static int cached = 0;
+    int dev = 0;
+    hipError_t q = hipGetDevice(&dev);
     if (q != hipSuccess) return q;
-    long long resident = (long long)per_cu * cus;
-    if (resident < 1) resident = 1;
+    long long resident = 0;
+    {
+        std::lock_guard<std::mutex> guard(cache_lock);
+        for (int i = 0; i < cached; i++)
+            if (cache[i].dev == dev && cache[i].fn == fn && cache[i].lds == lds_bytes) resident = cache[i].groups;
+    }
+    if (resident == 0) {
+        int per_cu = 0, cus = 0;
+        q = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (q != hipSuccess) return q;
+        if (lds_bytes > 48 * 1024) {   // beyond the default cap on dynamic LDS per workgroup (a tree of more than 1023 nodes)
+            q = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (q != hipSuccess) return q;
+        }
+        q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WAVES_PER_GROUP, lds_bytes);
+        if (q != hipSuccess) return q;
+        resident = (long long)per_cu * cus;
+        if (resident < 1) resident = 1;
+        std::lock_guard<std::mutex> guard(cache_lock);
+        if (cached < 32) cache[cached++] = Resident{dev, fn, lds_bytes, resident};
+    }
     const dim3 pgrid((unsigned)(groups < resident ? groups : resident));
     void *kargs[] = {(void *)&args};
     return hipLaunchKernel(fn, pgrid, block, kargs, lds_bytes, stream);

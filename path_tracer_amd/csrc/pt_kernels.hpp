@@ -31,6 +31,8 @@ int tiles_for(const ptd::Camera &cam, int lanes);
 hipError_t launch_unary_selftest(int fn, unsigned long long *d_count, hipStream_t stream);
 // counts the operand pairs (2^log2_pairs of them) on which the reciprocal-based division differs from x / a
 hipError_t launch_division_selftest(int log2_pairs, unsigned long long *d_count, hipStream_t stream);
+// `groups` workgroups of 4 waves, each leaving {shader cycles, 100 MHz ticks} of a multiply chain of `iters` rounds in d_stamps
+hipError_t launch_clock_probe(unsigned long long *d_stamps, float *d_sink, int groups, int iters, hipStream_t stream);
 hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, float inv_w, float inv_h, unsigned long long *d_count,
                                 hipStream_t stream);
 hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
@@ -38,6 +40,10 @@ hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const Rende
 size_t sched_bytes(const ptd::Camera &cam);
 // address and size of the library's file-scope scratch array on the current device (pt_render_device_static)
 hipError_t static_sched(int device, int32_t **out, size_t *bytes);
+// the array's in-flight record, shared by every context of the device: *busy = its previous launch went to another
+// stream and has not completed; static_mark records the launch just enqueued on `stream` as the most recent one
+hipError_t static_claim(int device, hipStream_t stream, bool *busy);
+hipError_t static_mark(int device, hipStream_t stream);
 hipError_t launch_primary_hits(const ptd::Scene &sc, const ptd::Camera &cam, int S, int sample, int32_t *d_hit_id,
                                float *d_hit_t, hipStream_t stream);
 hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t *d_rgb8, hipStream_t stream);

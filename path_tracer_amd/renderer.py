@@ -156,6 +156,12 @@ class ParallelRenderer:
             _abi.check(self._ctx, -2)        # PT_ERR_HIP with the kernel's message
         return ms
 
+    def clock_probe(self):
+        """pt_clock_probe: the GPU's shader clock right now, in GHz (a 2 ms chip-filling multiply chain)."""
+        ghz = C.c_float(0.0)
+        _abi.check(self._ctx, _abi.lib().pt_clock_probe(self._ctx, C.byref(ghz)))
+        return float(ghz.value)
+
     def selftest_grid(self, samples):
         """pt_selftest_grid for the bound camera: sample-grid coordinates that differ from the
         reference's IEEE divisions (must be 0)."""
@@ -254,6 +260,30 @@ class RendererGroup:
         self._check(_abi.lib().pt_group_render(self._grp, s, int(seed) & (2 ** 64 - 1), buffer.ctypes.data,
                                                rad.ctypes.data if rad is not None else None))
         return (buffer, rad) if radiance else buffer
+
+    def context(self, rank):
+        """the borrowed pt_context of GPU `rank` (pt_group_context)"""
+        return C.c_void_p(_abi.lib().pt_group_context(self._grp, int(rank)))
+
+    def set_timeout(self, milliseconds):
+        """pt_group_set_timeout: longest wait of a render for its GPUs (0 = no limit)"""
+        self._check(_abi.lib().pt_group_set_timeout(self._grp, int(milliseconds)))
+
+    def rccl_version(self):
+        """(compiled against, loaded) NCCL version codes (pt_group_rccl_version)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(_abi.lib().pt_group_rccl_version(self._grp, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def inject_fault(self, rank, kind):
+        """pt_group_inject_fault (test hook, host side only)"""
+        self._check(_abi.lib().pt_group_inject_fault(self._grp, int(rank), int(kind)))
+
+    def clock_probe(self, rank=0):
+        ghz = C.c_float(0.0)
+        ctx = self.context(rank)
+        _abi.check(ctx, _abi.lib().pt_clock_probe(ctx, C.byref(ghz)))
+        return float(ghz.value)
 
     def timings(self):
         """({rank: path-kernel ms}, reduce ms) of the last render."""

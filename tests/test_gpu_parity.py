@@ -162,6 +162,50 @@ def test_group_render_matches_oracle_shards(oracle):
             group.close()
 
 
+def test_group_wait_reports_a_failed_or_late_gpu_instead_of_hanging(oracle):
+    """The bounded wait of pt_group_render (hipStreamQuery + ncclCommGetAsyncError per GPU): a GPU that reports an
+    asynchronous RCCL error, or does not finish within the group's timeout, comes back as PT_ERR_HIP naming it; the
+    communicators are aborted, the group refuses further renders, and destroying it returns.  The faults are
+    injected on the host side of the poll (pt_group_inject_fault): nothing is provoked on the GPU."""
+    import path_tracer_amd as pt
+    rt = make_raytracer("rtow", 160, 90, 4)
+    osc = oracle.OracleScene(rt.packed)
+    for kind, word in ((1, "asynchronous error"), (2, "had not finished")):
+        group = pt.RendererGroup.new([0])
+        try:
+            compiled, loaded = group.rccl_version()
+            assert compiled // 10000 == loaded // 10000 == 2            # the same major version answers
+            group.set_lanes_per_pixel(1)
+            img = group.render(rt, seed=RENDER_SEED)                    # a good frame first
+            assert np.array_equal(img, osc.resolve(osc.render(rt.camera.pod, 4, seed=RENDER_SEED)["radiance"], 4))
+            with pytest.raises(pt.PtError):
+                group.set_timeout(-1)
+            with pytest.raises(pt.PtError):
+                group.inject_fault(1, 1)                                # no such GPU in a group of one
+            group.set_timeout(300)
+            group.inject_fault(0, kind)
+            with pytest.raises(pt.PtError) as err:
+                group.render(rt, seed=RENDER_SEED)
+            assert err.value.code == -2 and "GPU 0" in str(err.value) and word in str(err.value)
+            with pytest.raises(pt.PtError) as err:                      # the group is gone, and says so
+                group.render(rt, seed=RENDER_SEED)
+            assert err.value.code == -2 and "aborted" in str(err.value)
+        finally:
+            group.close()                                               # returns: the stream did drain
+    # a fresh group on the same GPU works after the aborts
+    group = pt.RendererGroup.new([0])
+    try:
+        group.set_lanes_per_pixel(1)
+        assert np.array_equal(group.render(rt, seed=RENDER_SEED), img)
+    finally:
+        group.close()
+
+
+def test_clock_probe_reads_a_plausible_shader_clock(renderer):
+    ghz = renderer.clock_probe()
+    assert 0.8 < ghz < 2.6, ghz            # MI355X: up to 2.4 GHz, lower under load
+
+
 def test_stream_ordered_render_reduce_resolve_equals_render(renderer, oracle):
     """The one-process-per-GPU step of bench.py with a single rank: render_device -> (reduce) -> resolve_device
     -> D2H, all on ONE non-default torch stream, equals pt_render's image."""

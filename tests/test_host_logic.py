@@ -236,6 +236,15 @@ def test_group_shard_partitions_the_grid():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_group_shard_bad_arguments_give_the_empty_range():
+    """n < 1 (a division by zero before round 3) or a rank outside [0, n): [0, 0), never a signal"""
+    for samples, rank, n in ((8, 0, 0), (8, 0, -3), (8, -1, 4), (8, 4, 4), (8, 9, 4), (-2, 0, 1)):
+        assert pt.group_shard(samples, rank, n) == (0, 0)
+    b = C.c_int32(7)
+    pt.lib().pt_group_shard(8, 0, 0, C.byref(b), None)             # NULL outputs are allowed
+    assert b.value == 0
+
+
 def test_group_create_argument_errors():
     lib = pt.lib()
     out = C.c_void_p()
@@ -244,6 +253,8 @@ def test_group_create_argument_errors():
     assert lib.pt_group_create(two, 2, C.byref(out)) == -1          # a device listed twice
     assert b"twice" in lib.pt_group_last_error(None)
     assert lib.pt_group_size(None) == 0 and not lib.pt_group_context(None, 0)
+    assert lib.pt_group_set_timeout(None, 5) == -1 and lib.pt_group_inject_fault(None, 0, 1) == -1
+    assert lib.pt_group_rccl_version(None, None, None) == -1 and lib.pt_clock_probe(None, None) == -1
 
 
 def _c_structs(header):
