@@ -237,6 +237,24 @@ enum { PT_WALK_REFERENCE = 0, PT_WALK_VIEW = 1 };
 int pt_set_walk_order(pt_context *ctx, int32_t order);
 int pt_get_walk_order(const pt_context *ctx);   /* the order in effect for the uploaded scene */
 
+/* Primary-ray candidate lists.  No counterpart in the reference, whose every ray walks the tree from the root
+ * (src/scene/mod.rs:24-34 -> src/scene/bvh.rs:106-127).  For every 8x8 pixel block of the camera's frame the library
+ * lists the spheres a camera ray through the block can possibly hit (2.2 on average on the bench scenes): those whose
+ * ball, inflated by a margin a hundred times the fp32 rounding of the kernel's own rays and tests, meets the block's
+ * cone of directions (src/raytracer.rs:77-85, src/math/camera.rs:37-44).  A primary ray then runs Sphere::trace on
+ * that handful, in rank order with the same tie rule, instead of walking the tree -- 21.6 box tests per path fewer on
+ * the bench scene.  The closest hit, hence the radiance, is the same bit for bit: a sphere outside the list cannot be
+ * hit, and a box test never changes which hit is closest while every box contains what is below it -- the lists are
+ * only built for such trees (as PT_WALK_VIEW, below), never for pt_upload_scene_ext scenes, and a block with more
+ * than 8 candidates walks the tree.  What it shares with PT_WALK_VIEW's fine point (2): a hit within an fp32 rounding
+ * error of the very point where a sphere touches one of its boxes, on a ray that also grazes that box within rounding,
+ * could be rejected by the reference's box test and is accepted here (about 1e-13 per segment; never observed).
+ * The hit-id AOV always walks the tree.  Rebuilt (a GPU kernel, then a stream sync) by pt_set_camera / pt_upload_scene /
+ * pt_set_walk_order.  enabled = 0 turns the lists off (every ray walks the tree); default on.
+ * pt_get_primary_lists: 1 if the uploaded scene + camera render with lists, 0 if not. */
+int pt_set_primary_lists(pt_context *ctx, int32_t enabled);
+int pt_get_primary_lists(const pt_context *ctx);
+
 /* The shader clock of the context's GPU right now, in GHz: a two-millisecond chip-filling chain of fp32
  * multiplies (its own small kernel, 8 waves per SIMD like the path kernel) stamped with the shader-cycle
  * counter and the constant 100 MHz counter; the median over its workgroups of cycles per tick.  No

@@ -23,7 +23,11 @@ thread_local std::string g_create_error;
 constexpr int64_t kFullChipLanes = 256ll * 4 * 8 * 64;
 // n0[] entries (16 B each) a workgroup stages in LDS: 16 KiB, so LDS (160 KiB per CU)
 // never limits residency below the 8 workgroups x 4 waves a CU can hold
-constexpr int32_t kMaxLdsNodes = 2048;   // = PT_LDS_N1_OFFSET / 16 (pt_kernels.hip): both halves of these nodes sit in LDS, 64 KiB per group
+constexpr int32_t kMaxLdsNodes = PT_MAX_LDS_NODES;   // both halves of these nodes sit in LDS (pt_kernels.hpp: 64 KiB per group, the waves' chains at the top)
+// Slots of the device node arrays: a tree that fits is numbered 0 .. n-1; a larger one keeps kMaxLdsNodes staged nodes in
+// slots 0 .. kMaxLdsNodes-1 and the others from PT_FIRST_GLOBAL_SLOT on (the slots between are never used), so that a
+// byte offset below PT_LDS_N1_OFFSET always means LDS.
+int32_t slots_for(int32_t n_nodes) { return n_nodes <= kMaxLdsNodes ? n_nodes : PT_FIRST_GLOBAL_SLOT + (n_nodes - kMaxLdsNodes); }
 
 }  // namespace
 
@@ -93,6 +97,8 @@ void free_scene(pt_context *c)
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_prim_ids) (void)hipFree(c->d_prim_ids);
     c->d_prim_ids = nullptr;
+    if (c->d_leaf_codes) (void)hipFree(c->d_leaf_codes);
+    c->d_leaf_codes = nullptr;
     if (c->d_textures) (void)hipFree(c->d_textures);
     if (c->d_xforms) (void)hipFree(c->d_xforms);
     for (uint8_t *p : c->d_texels) (void)hipFree(p);
@@ -185,8 +191,9 @@ int thread_nodes(pt_context *c)
     const float eye[3] = {c->camera.origin.x, c->camera.origin.y, c->camera.origin.z};
     if (c->threaded && c->threaded_view == view && (!view || std::memcmp(eye, c->threaded_eye, sizeof eye) == 0)) return PT_OK;
 
-    std::vector<int32_t> slot, order, first, second, succ, walk, stack;
+    std::vector<int32_t> slot, order, first, second, succ, walk, stack, leaf_codes;
     std::vector<float4> h_nodes;
+    const int32_t n_slots = slots_for(n_nodes);
     try {
         slot.resize((size_t)n_nodes);
         order.reserve((size_t)n_nodes);
@@ -195,7 +202,8 @@ int thread_nodes(pt_context *c)
         succ.assign((size_t)n_nodes, n_nodes);
         walk.reserve((size_t)n_nodes);
         stack.reserve(64);
-        h_nodes.resize(2 * (size_t)n_nodes);
+        h_nodes.assign(2 * (size_t)slots_for(n_nodes), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        leaf_codes.assign((size_t)c->scene.n_spheres, 0);
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
@@ -294,15 +302,16 @@ int thread_nodes(pt_context *c)
         int32_t next_slot = 0;
         for (int32_t q = 0; q < n_nodes; q++)           // the staged ones, breadth-first among themselves
             if (in_prefix[order[q]]) slot[order[q]] = next_slot++;
+        next_slot = PT_FIRST_GLOBAL_SLOT;
         for (int32_t i : walk)
             if (!in_prefix[i]) slot[i] = next_slot++;
     }
     // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
     auto code_of = [&](int32_t i) -> int32_t {
-        if (i >= n_nodes) return n_nodes << PT_CODE_SHIFT;
+        if (i >= n_nodes) return n_slots << PT_CODE_SHIFT;
         return nodes[i].prim >= 0 ? (int32_t)((uint32_t)(slot[i] << PT_CODE_SHIFT) | 0x80000000u) : (slot[i] << PT_CODE_SHIFT);
     };
-    float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_nodes;
+    float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_slots;
     for (int32_t i = 0; i < n_nodes; i++) {
         const pt_bvh_node &nd = nodes[i];
         float4 a, b;
@@ -317,6 +326,9 @@ int thread_nodes(pt_context *c)
             a = c->h_leaf[2 * (size_t)i];
             b = c->h_leaf[2 * (size_t)i + 1];
             std::memcpy(&b.w, &next, 4);
+            int32_t rank;
+            std::memcpy(&rank, &b.z, 4);
+            leaf_codes[(size_t)rank] = code_of(i);      // rank: validated at upload, one Leaf per primitive
         }
         h_n0[slot[i]] = a;
         h_n1[slot[i]] = b;
@@ -330,12 +342,54 @@ int thread_nodes(pt_context *c)
         PT_HIP(c, hipDeviceSynchronize());   // launches on caller streams (pt_render_device) may still be walking the old arrays
         c->threaded = false;                 // until the copy has succeeded the device arrays are in no known state
         PT_HIP(c, hipMemcpy(c->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+        PT_HIP(c, hipMemcpy(c->d_leaf_codes, leaf_codes.data(), leaf_codes.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         c->h_threaded.swap(h_nodes);
+        c->lists_valid = false;              // the lists hold node codes: new codes, new lists
     }
     c->scene.root_code = code_of(0);
     c->threaded = true;
     c->threaded_view = view;
     std::memcpy(c->threaded_eye, eye, sizeof eye);
+    return PT_OK;
+}
+
+// The primary-ray candidate lists of the current scene + camera (pt_kernels.hip primary_list_kernel; Scene::cand),
+// rebuilt whenever the camera, the scene or the node numbering changes.  Only for trees whose boxes contain what
+// is below them (view_ok: there a box test cannot change which hit is closest, so a camera ray's walk may skip the
+// boxes altogether) and never for the extension's scenes; pt_set_primary_lists(ctx, 0) turns them off.
+int build_primary_lists(pt_context *c)
+{
+    c->scene.cand = nullptr;
+    c->scene.cand_tiles_x = 0;
+    if (!c->have_scene || !c->have_camera || !c->primary_lists || !c->view_ok || c->scene.ext || !c->threaded) return PT_OK;
+    // the small-tree launch keeps the plain walk (pt_kernels.hip launch_path), and so does a scene x frame whose
+    // brute-force list build would take longer than it saves (a lane per block tests every sphere)
+    const int64_t blocks = (int64_t)((c->camera.width + 7) / 8) * ((c->camera.height + 7) / 8);
+    if (c->scene.n_nodes < 32 || blocks * c->scene.n_spheres > (int64_t)2e10) return PT_OK;
+    const size_t need = (size_t)blocks * PT_PRIMARY_K * sizeof(int32_t);
+    PT_HIP(c, hipSetDevice(c->device));
+    if (need > c->lists_bytes) {
+        int32_t *fresh = nullptr;
+        PT_HIP(c, hipMalloc((void **)&fresh, need));
+        hipError_t e = hipDeviceSynchronize();   // launches on caller streams may still be reading the old lists
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(c, PT_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e));
+        }
+        if (c->d_lists) (void)hipFree(c->d_lists);
+        c->d_lists = fresh;
+        c->lists_bytes = need;
+        c->lists_valid = false;
+    }
+    if (!c->lists_valid || std::memcmp(&c->lists_camera, &c->camera, sizeof c->camera) != 0) {
+        PT_HIP(c, hipDeviceSynchronize());
+        PT_HIP(c, ptk::launch_primary_lists(c->scene, c->camera, c->d_leaf_codes, c->scene.n_spheres, c->d_lists, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        c->lists_camera = c->camera;
+        c->lists_valid = true;
+    }
+    c->scene.cand = c->d_lists;
+    c->scene.cand_tiles_x = (c->camera.width + 7) / 8;
     return PT_OK;
 }
 
@@ -404,6 +458,7 @@ void pt_destroy(pt_context *c)
     free_scene(c);
     free_frame(c);
     if (c->d_sched) (void)hipFree(c->d_sched);
+    if (c->d_lists) (void)hipFree(c->d_lists);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->ev_own_done) (void)hipEventDestroy(c->ev_own_done);
@@ -572,7 +627,9 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     free_scene(c);
-    PT_HIP(c, hipMalloc((void **)&c->d_nodes, 2 * (size_t)n_nodes * sizeof(float4)));
+    const int32_t n_slots = slots_for(n_nodes);
+    PT_HIP(c, hipMalloc((void **)&c->d_nodes, 2 * (size_t)n_slots * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_leaf_codes, (size_t)n_prims * sizeof(int32_t)));
     PT_HIP(c, hipMalloc((void **)&c->d_prims, h_prims.size() * sizeof(float4)));
     PT_HIP(c, hipMemcpy(c->d_prims, h_prims.data(), h_prims.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMalloc((void **)&c->d_prim_ids, prim_ids.size() * sizeof(int32_t)));
@@ -603,14 +660,17 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
         PT_HIP(c, hipMemcpy(c->d_textures, h_tex.data(), h_tex.size() * sizeof(ptd::Texture), hipMemcpyHostToDevice));
     }
     c->scene.n0 = c->d_nodes;
-    c->scene.n1 = c->d_nodes + n_nodes;
+    c->scene.n1 = c->d_nodes + n_slots;
     c->scene.prims = c->d_prims;
     c->scene.prim_ids = c->d_prim_ids;
     c->scene.textures = c->d_textures;
     c->scene.xforms = c->d_xforms;
     c->scene.ext = ext ? 1 : 0;
     c->scene.lds_xforms = (ext && n_xforms <= 128) ? n_xforms : 0;   // 4 KiB of LDS at most; more: read through the L1
-    c->scene.n_nodes = n_nodes;
+    c->scene.n_nodes = n_slots;              // slots, not nodes: the code 16 * n_slots ends a walk and bounds the arrays
+    c->scene.cand = nullptr;
+    c->scene.cand_tiles_x = 0;
+    c->lists_valid = false;
     c->scene.n_spheres = n_prims;
     c->scene.lds_nodes = n_nodes < kMaxLdsNodes ? n_nodes : kMaxLdsNodes;
     // regular_ray (pt_device.hpp): the short division needs every sphere inside 2^32 (NaN fails the test)
@@ -628,10 +688,10 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     c->h_leaf.swap(h_leaf);
     c->threaded = false;
     c->h_threaded.clear();
-    const int rc = thread_nodes(c);
+    int rc = thread_nodes(c);
     if (rc != PT_OK) return rc;
     c->have_scene = true;
-    return PT_OK;
+    return build_primary_lists(c);
 }
 
 int pt_upload_scene(pt_context *c, const pt_sphere *spheres, int32_t n_spheres, const pt_material *materials,
@@ -737,10 +797,13 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
     c->camera = next;
     c->have_camera = true;
     if (c->have_scene) {
-        const int rc = thread_nodes(c);
+        int rc = thread_nodes(c);
+        if (rc == PT_OK) rc = build_primary_lists(c);
         if (rc != PT_OK) {
             c->camera = previous;
             c->have_camera = had_camera;
+            c->scene.cand = nullptr;             // lists of another camera are never used: the plain walk until the next success
+            c->lists_valid = false;
             return rc;
         }
     }
@@ -864,8 +927,24 @@ int pt_set_walk_order(pt_context *c, int32_t order)
     if (order != PT_WALK_REFERENCE && order != PT_WALK_VIEW)
         return fail(c, PT_ERR_INVALID, "walk order must be PT_WALK_REFERENCE (0) or PT_WALK_VIEW (1), got %d", order);
     c->walk_order = order;
-    if (c->have_scene) return thread_nodes(c);
+    if (c->have_scene) {
+        const int rc = thread_nodes(c);
+        return rc != PT_OK ? rc : build_primary_lists(c);
+    }
     return PT_OK;
+}
+
+int pt_set_primary_lists(pt_context *c, int32_t enabled)
+{
+    if (!c) return PT_ERR_INVALID;
+    c->primary_lists = enabled != 0;
+    return build_primary_lists(c);
+}
+
+int pt_get_primary_lists(const pt_context *c)
+{
+    if (!c) return PT_ERR_INVALID;
+    return c->scene.cand != nullptr ? 1 : 0;
 }
 
 int pt_get_walk_order(const pt_context *c)

@@ -50,6 +50,14 @@ struct pt_context {
     bool threaded = false, threaded_view = false;   // what d_nodes holds now
     float threaded_eye[3] = {0.0f, 0.0f, 0.0f};
 
+    // primary-ray candidate lists (pt_api.cpp build_primary_lists; Scene::cand)
+    int32_t *d_leaf_codes = nullptr;     // per primitive rank: the code of its Leaf in the current threading
+    int32_t *d_lists = nullptr;          // per 8x8 pixel block of the camera's frame: PT_PRIMARY_K codes
+    size_t lists_bytes = 0;
+    bool lists_valid = false;            // d_lists was built for lists_camera and the current node codes
+    ptd::Camera lists_camera{};
+    bool primary_lists = true;           // pt_set_primary_lists
+
     int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
     size_t sched_bytes = 0;
     // the device's copy of the library's file-scope scratch array (pt_render_device_static), resolved in pt_create

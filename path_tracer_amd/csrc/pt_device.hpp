@@ -34,6 +34,11 @@ struct Scene {
     const float4 *xforms;    // per transform: (offset.xyz, sin theta), (cos theta, -, -, -)
     int32_t ext;             // 1: rendered by the extension's kernel instantiation
     int32_t lds_xforms;      // the path kernel stages this many transforms (all of them, or 0) in LDS behind the nodes
+    // Primary-ray candidate lists (pt_kernels.hip primary_list_kernel), or NULL: per 8x8 pixel block of the current
+    // camera's frame, PT_PRIMARY_K leaf codes -- every sphere a camera ray through the block can possibly hit --
+    // ended by 0; a first entry of 1 = too many: walk the tree.  cand_tiles_x = blocks per row.
+    const int32_t *cand;
+    int32_t cand_tiles_x;
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;

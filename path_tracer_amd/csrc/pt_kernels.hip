@@ -103,10 +103,7 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 // Against one workgroup of 4 waves per 4 items (the round-1 launch: 516 ms for the headline frame) no wave slot
 // waits for the slowest wave of its group and the tree is staged once per slot instead of once per item: 492 ms
 // at any group size (4, 8, 16 waves).
-#ifndef PT_WAVES_PER_GROUP
-#define PT_WAVES_PER_GROUP 16
-#endif
-constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
+constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;   // pt_kernels.hpp
 // BOTH halves of a staged node sit in LDS -- n0[] from byte 0, n1[] from byte N1OFF of the group's allocation (a
 // template parameter: PT_LDS_N1_OFFSET for the persistent launch, PT_SMALL_N1_OFFSET for the small-tree one) -- so
 // a visit of a staged node makes no vector-memory access at all: 482 ms.  (Without the persistent launch it did
@@ -118,7 +115,6 @@ constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;
 #ifndef PT_SMALL_TREE
 #define PT_SMALL_TREE 32   // nodes; below it the launch without the item loop (launch_path)
 #endif
-#define PT_LDS_N1_OFFSET 32768   // = 16 * kMaxLdsNodes (pt_api.cpp)
 #define PT_SMALL_N1_OFFSET (16 * PT_SMALL_TREE)
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
@@ -327,7 +323,8 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const v4f lds_f4;
     auto lds_read = [](uint32_t addr) -> float4 { const v4f t = *(lds_f4 *)(uintptr_t)addr; return make_float4(t.x, t.y, t.z, t.w); };
-    const int lds_nodes = sc.lds_nodes;
+    typedef __attribute__((address_space(3))) v4f lds_f4_rw;
+    auto lds_write = [](uint32_t addr, float4 v) { v4f t = {v.x, v.y, v.z, v.w}; *(lds_f4_rw *)(uintptr_t)addr = t; };
     (void)xf_lds;
     const int lane = threadIdx.x & 63;
     const int L = rp.lanes;
@@ -406,7 +403,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     // SPLIT_ONLY: the caller knows c is a Split code (no Leaf flag to mask)
     auto fetch = [&](int32_t c, float4 &n0, float4 &n1, const bool SPLIT_ONLY = false) {
         const int off = SPLIT_ONLY ? (c << (4 - PT_CODE_SHIFT)) : code_offset(c);
-        if (ALL_IN_LDS || off < (lds_nodes << 4)) {
+        if (ALL_IN_LDS || off < N1OFF) {   // every offset below N1OFF is an LDS address: a staged node or an entry of the wave's chain
             n0 = lds_read((uint32_t)off);
             n1 = lds_read((uint32_t)off + (uint32_t)N1OFF);
             if (!ALL_IN_LDS) asm volatile("" : "+v"(n0.x), "+v"(n1.x));
@@ -417,6 +414,36 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         }
     };
     auto lanes = [&](bool p) -> int { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(p))); };
+
+    // Where a PRIMARY ray's walk starts.  A camera ray through this wave's pixels can only hit the few spheres
+    // whose (slightly inflated) balls meet the pixel block's frustum: primary_list_kernel lists their Leaves per 8x8
+    // pixel block (2.2 on average on the bench scenes; Scene::cand).  The wave copies its block's Leaves into a
+    // chain of its own in LDS -- same node format, each entry's `next` the following entry, the last one's the end
+    // code -- and its primary rays walk that chain instead of the tree: the same Sphere::trace per candidate, in
+    // the same order of ranks, without the 21.6 box tests a walk from the root spends on finding them.  The closest
+    // hit is the same: a sphere that is not in the list cannot be hit by a ray of the block, and a box test never
+    // changes which hit is closest as long as boxes contain what is below them (the host only builds lists for such
+    // trees).  A block with more than PT_PRIMARY_K candidates walks the tree as before.
+    int32_t primary_code = sc.root_code;
+    if (N1OFF == PT_LDS_N1_OFFSET && !EXT && sc.cand) {
+        const int ctile = ((tile / tiles_x) * th >> 3) * sc.cand_tiles_x + ((tile % tiles_x) * tw >> 3);
+        const int32_t mine = lane < PT_PRIMARY_K ? sc.cand[(size_t)ctile * PT_PRIMARY_K + lane] : 0;
+        const int32_t first = __builtin_amdgcn_readfirstlane(mine);
+        if (first != 1) {                                                        // 1: too many candidates, walk the tree
+            const int count = lanes(mine != 0);
+            const uint32_t chain = (uint32_t)(PT_CHAIN_BASE + (threadIdx.x >> 6) * (16 * PT_PRIMARY_K));
+            if (mine != 0) {
+                float4 n0, n1;
+                fetch(mine, n0, n1);
+                const int32_t next = lane + 1 < count ? (int32_t)((chain + 16u * (uint32_t)(lane + 1)) | 0x80000000u) : n_nodes;
+                n1.w = __int_as_float(next);
+                lds_write(chain + 16u * (uint32_t)lane, n0);
+                lds_write(chain + 16u * (uint32_t)lane + (uint32_t)N1OFF, n1);
+            }
+            primary_code = count > 0 ? (int32_t)(chain | 0x80000000u) : n_nodes;     // no candidate: the ray misses everything
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
 
     // SPLIT and LEAF steps go straight back to the vote; SHADE falls through to
     // the shared tails: new_path -> the next sample's camera ray (or DONE),
@@ -464,7 +491,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
 #endif
             regular = regular_ray(inv, ray.o, a, sc.bounded != 0);
             h.t = T_MAX; h.prim = -1;
-            code = sc.root_code;
+            code = new_path ? primary_code : sc.root_code;
         }
         new_path = false; new_walk = false;
         PT_TIME(5);
@@ -775,6 +802,74 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
     rgb8[3 * i + 2] = trunc_sat_u8(c.z);
 }
 
+// The primary-ray candidate lists (Scene::cand): one lane per 8x8 pixel block of the frame.  No counterpart in the
+// reference, whose every ray walks the tree from the root (scene/mod.rs:24-34); what a list holds is the set of
+// Leaves that walk can end on for the camera rays of the block (raytracer.rs:77-85 + camera.rs:37-44).
+//
+// The block's camera rays leave the eye inside the cone over a parallelogram of directions -- dir(u, v) is
+// affine in (u, v), u in [x0, x0 + 8] / W, v in 1 - [y0, y0 + 8] / H (a pixel's sample offsets run over [0, 1]).
+// A ray inside the cone can only meet a sphere whose centre lies within its radius of the cone, hence within
+// its radius of the inner half-space of each of the cone's four side planes.  A sphere is LEFT OUT only on proof:
+// its centre is farther than radius + margin outside one of the planes, evaluated in fp64, where the margin
+// covers, a hundred times over, everything fp32 does to the kernel's own rays and tests:
+//   * the direction the kernel computes differs from the affine one by at most ~1e-6 (|llc| + |horizontal| +
+//     |vertical| + |origin|) in each component (four roundings of terms of that size, and u, v carry 2^-24 relative
+//     errors of their own): an angle of at most that over the distance to the image plane -- `theta`, taken 10 x larger;
+//   * Sphere::trace's discriminant b^2 - a c carries an absolute error of a few 2^-24 |oc|^2 |d|^2, so it can come out
+//     positive for a ray that passes the centre at up to sqrt(r^2 + 5e-7 D^2) <= r + 2.5e-7 D^2 / r: taken as
+//     r (1 + 1e-4) + 1e-5 D^2 / r (a vanishing radius keeps its sphere in every list).
+// Every comparison is written so that a NaN keeps the sphere, and a camera whose cone cannot be formed (degenerate
+// or non-finite fields) marks the block "walk the tree".  The lists come out in rank order.
+__global__ __launch_bounds__(64) void primary_list_kernel(Scene sc, Camera cam, const int32_t *__restrict__ leaf_codes, int n_leaves,
+                                                          int blocks_x, int blocks_y, int32_t *__restrict__ lists)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= blocks_x * blocks_y) return;
+    int32_t *out = lists + (size_t)t * PT_PRIMARY_K;
+    const int bx = t % blocks_x, by = t / blocks_x;
+    struct d3 { double x, y, z; };
+    auto D3 = [](f3 a) { d3 r = {(double)a.x, (double)a.y, (double)a.z}; return r; };
+    auto dotd = [](d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    auto crossd = [](d3 a, d3 b) { d3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; return r; };
+    auto norm1 = [](d3 a) { return __builtin_fabs(a.x) + __builtin_fabs(a.y) + __builtin_fabs(a.z); };
+    const d3 llc = D3(cam.llc), o = D3(cam.origin), H = D3(cam.horizontal), V = D3(cam.vertical);
+    const double u0 = (double)(bx * 8) / (double)cam.width, u1 = (double)(bx * 8 + 8) / (double)cam.width;
+    const double v1 = 1.0 - (double)(by * 8) / (double)cam.height, v0 = 1.0 - (double)(by * 8 + 8) / (double)cam.height;
+    auto corner = [&](double u, double v) { d3 r = {llc.x + H.x * u + V.x * v - o.x, llc.y + H.y * u + V.y * v - o.y, llc.z + H.z * u + V.z * v - o.z}; return r; };
+    const d3 c[4] = {corner(u0, v0), corner(u1, v0), corner(u1, v1), corner(u0, v1)};
+    const d3 centre = {c[0].x + c[1].x + c[2].x + c[3].x, c[0].y + c[1].y + c[2].y + c[3].y, c[0].z + c[1].z + c[2].z + c[3].z};
+    // the image plane's distance from the eye bounds |dir| from below over the whole block
+    d3 ip = crossd(H, V);
+    const double ipl = __builtin_sqrt(dotd(ip, ip));
+    const double focal = __builtin_fabs(dotd(ip, c[0])) / ipl;
+    const double theta = 1e-5 * (norm1(llc) + norm1(H) + norm1(V) + norm1(o)) / focal;
+    bool cone_ok = theta < 1e-2 && ipl > 0.0;                                   // false for NaN as well
+    d3 n[4];
+    for (int k = 0; k < 4; k++) {
+        d3 m = crossd(c[k], c[(k + 1) & 3]);
+        const double len = __builtin_sqrt(dotd(m, m));
+        double sgn = dotd(m, centre);
+        cone_ok = cone_ok && len > 0.0 && __builtin_isfinite(len) && (sgn > 0.0 || sgn < 0.0);
+        sgn = sgn < 0.0 ? -1.0 / len : 1.0 / len;                               // inward unit normal
+        n[k].x = m.x * sgn; n[k].y = m.y * sgn; n[k].z = m.z * sgn;
+    }
+    if (!cone_ok) { out[0] = 1; return; }
+    int count = 0;
+    for (int i = 0; i < n_leaves; i++) {
+        const int32_t code = leaf_codes[i];
+        const float4 s = sc.n0[code_index(code)];                               // (centre, radius^2)
+        const d3 oc = {(double)s.x - o.x, (double)s.y - o.y, (double)s.z - o.z};
+        const double r = __builtin_sqrt((double)s.w), D2 = dotd(oc, oc);
+        const double reach = r * (1.0 + 1e-4) + 1e-5 * D2 / r + theta * __builtin_sqrt(D2);
+        bool out_of_cone = false;
+        for (int k = 0; k < 4; k++) out_of_cone = out_of_cone || dotd(n[k], oc) < -reach;   // NaN: not proven outside
+        if (out_of_cone) continue;
+        if (count == PT_PRIMARY_K) { out[0] = 1; return; }
+        out[count++] = code;
+    }
+    for (int k = count; k < PT_PRIMARY_K; k++) out[k] = 0;                      // the path kernel reads all PT_PRIMARY_K entries
+}
+
 // pt_selftest_unary: one fp32 bit pattern per lane
 template <int FN>
 __global__ __launch_bounds__(256) void unary_selftest_kernel(unsigned long long *count, uint32_t base)
@@ -959,6 +1054,15 @@ hipError_t static_mark(int device, hipStream_t stream)
     return hipSuccess;
 }
 
+hipError_t launch_primary_lists(const Scene &sc, const Camera &cam, const int32_t *d_leaf_codes, int n_leaves, int32_t *d_lists,
+                                hipStream_t stream)
+{
+    const int bx = (cam.width + 7) / 8, by = (cam.height + 7) / 8;
+    hipLaunchKernelGGL(primary_list_kernel, dim3((unsigned)((bx * by + 63) / 64)), dim3(64), 0, stream, sc, cam, d_leaf_codes, n_leaves, bx,
+                       by, d_lists);
+    return hipGetLastError();
+}
+
 hipError_t launch_clock_probe(unsigned long long *d_stamps, float *d_sink, int groups, int iters, hipStream_t stream)
 {
     hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)groups), dim3(256), 0, stream, d_stamps, d_sink, iters);
@@ -1055,8 +1159,9 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
         hipLaunchKernelGGL((path_kernel<false>), grid, block, group_lds_bytes(sc, PT_SMALL_N1_OFFSET), stream, sc, cam, rp, sp, d_radiance);
         return hipGetLastError();
     }
-    if (sc.lds_nodes * 16 > PT_LDS_N1_OFFSET) return hipErrorInvalidValue;   // pt_api.cpp stages at most kMaxLdsNodes
-    const size_t lds_bytes = group_lds_bytes(sc, PT_LDS_N1_OFFSET);
+    if (sc.lds_nodes > PT_MAX_LDS_NODES) return hipErrorInvalidValue;   // pt_api.cpp stages at most that many
+    size_t lds_bytes = group_lds_bytes(sc, PT_LDS_N1_OFFSET);
+    if (sc.cand && !sc.ext && lds_bytes < 2 * (size_t)PT_LDS_N1_OFFSET) lds_bytes = 2 * (size_t)PT_LDS_N1_OFFSET;   // the waves' chains sit at the top of each half
     const long long groups = (items + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP;
     const dim3 block(64 * WAVES_PER_GROUP);
     // as many workgroups as the chip holds at once; each wave draws items until none are left

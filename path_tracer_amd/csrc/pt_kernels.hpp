@@ -2,6 +2,20 @@
 #pragma once
 #include "pt_device.hpp"
 
+// ---- LDS layout of a path-kernel workgroup, shared by the kernels (pt_kernels.hip) and the host's node numbering (pt_api.cpp)
+#ifndef PT_WAVES_PER_GROUP
+#define PT_WAVES_PER_GROUP 16
+#endif
+#define PT_LDS_N1_OFFSET 32768   // n0[] of the staged nodes from byte 0 of the group's allocation, n1[] from here
+#define PT_PRIMARY_K 8           // primary-ray candidates per 8x8 pixel block (Scene::cand); more: that block walks the tree
+// each wave's chain of candidate leaves: PT_PRIMARY_K node entries at the TOP of each half (n0 part below
+// PT_LDS_N1_OFFSET, n1 part PT_LDS_N1_OFFSET behind it, like any staged node)
+#define PT_CHAIN_BYTES (16 * PT_PRIMARY_K * PT_WAVES_PER_GROUP)
+#define PT_CHAIN_BASE (PT_LDS_N1_OFFSET - PT_CHAIN_BYTES)
+#define PT_MAX_LDS_NODES (PT_CHAIN_BASE / 16)        // 1920 nodes staged at most
+#define PT_FIRST_GLOBAL_SLOT (PT_LDS_N1_OFFSET / 16)  // a node that is not staged has a slot from here on: every byte offset
+                                                      // below PT_LDS_N1_OFFSET is an LDS address (staged node or chain entry)
+
 struct RenderParams {
     uint64_t seed;
     int32_t S;            // side of the sample grid (raytracer.rs:77-81); spp = S*S
@@ -46,6 +60,9 @@ hipError_t static_claim(int device, hipStream_t stream, bool *busy);
 hipError_t static_mark(int device, hipStream_t stream);
 hipError_t launch_primary_hits(const ptd::Scene &sc, const ptd::Camera &cam, int S, int sample, int32_t *d_hit_id,
                                float *d_hit_t, hipStream_t stream);
+// fills lists[blocks_x * blocks_y][PT_PRIMARY_K] for the camera (Scene::cand); leaf_codes[rank] = code of the primitive's Leaf
+hipError_t launch_primary_lists(const ptd::Scene &sc, const ptd::Camera &cam, const int32_t *d_leaf_codes, int n_leaves,
+                                int32_t *d_lists, hipStream_t stream);
 hipError_t launch_resolve(const float *d_radiance, int n_pixels, int S, uint8_t *d_rgb8, hipStream_t stream);
 }  // namespace ptk
 

@@ -83,6 +83,14 @@ class ParallelRenderer:
         PT_WALK_REFERENCE (left child first, bvh.rs:111-118).  Same results either way."""
         _abi.check(self._ctx, _abi.lib().pt_set_walk_order(self._ctx, _abi.PT_WALK_VIEW if view else _abi.PT_WALK_REFERENCE))
 
+    def set_primary_lists(self, enabled):
+        """pt_set_primary_lists: per-block candidate lists for camera rays (default on); off = every ray walks the tree"""
+        _abi.check(self._ctx, _abi.lib().pt_set_primary_lists(self._ctx, 1 if enabled else 0))
+
+    def primary_lists(self):
+        """True if the bound scene + camera render with primary-ray candidate lists"""
+        return _abi.lib().pt_get_primary_lists(self._ctx) == 1
+
     def walk_order(self):
         """the order in effect for the uploaded scene (scenes that can tie keep the reference's)"""
         return _abi.lib().pt_get_walk_order(self._ctx)

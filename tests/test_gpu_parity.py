@@ -743,3 +743,76 @@ def test_boxes_that_do_not_contain_their_spheres_keep_the_reference_order(render
         assert np.array_equal(ids, ref["hit_id"])
         lanes = renderer.lanes_per_pixel(4, 0, 16)
         assert same_bits(rad, osc.render(cam.pod, 4, seed=2, chunk=-(-16 // lanes))["radiance"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,s,lanes", [("rtow", 320, 180, 4, 1), ("rtow", 200, 120, 4, 0), ("reference", 256, 144, 3, 1)])
+def test_primary_lists_on_and_off_agree(renderer, oracle, kind, w, h, s, lanes):
+    """pt_set_primary_lists: camera rays that test their pixel block's candidate spheres instead of walking the tree
+    return the oracle's radiance bit for bit, as the plain walk does; the hit-id AOV (always a walk) agrees too."""
+    rt = make_raytracer(kind, w, h, s)
+    osc = oracle.OracleScene(rt.packed)
+    renderer.set_lanes_per_pixel(lanes)
+    try:
+        for on in (True, False, True):
+            renderer.set_primary_lists(on)
+            img, rad, ids = renderer.render(rt, seed=RENDER_SEED, radiance=True, hit_ids=True)
+            assert renderer.primary_lists() == on
+            used = renderer.lanes_per_pixel(s, 0, s * s)
+            ref = osc.render(rt.camera.pod, s, seed=RENDER_SEED, chunk=-(-(s * s) // used), hit_ids=True)
+            assert same_bits(rad, ref["radiance"]), "lists %s: %d radiance words differ" % (on, np.sum(rad.view(np.uint32) != ref["radiance"].view(np.uint32)))
+            assert np.array_equal(ids, ref["hit_id"])
+    finally:
+        renderer.set_primary_lists(True)
+        renderer.set_lanes_per_pixel(0)
+
+
+@pytest.mark.gpu
+def test_primary_lists_crowded_blocks_eye_inside_a_sphere_and_duplicates(renderer, oracle):
+    """Blocks with more candidates than a list holds (a row of spheres seen end on) walk the tree; an eye inside a
+    glass sphere, spheres behind the eye, duplicated spheres (exact ties) and a huge ground sphere all come out as
+    the oracle's, from several eyes, with lists on."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, -1000.3, 0.0), 1000.0, pt.Lambertian.new_solid((0.5, 0.5, 0.5))))
+    for k in range(2, 42):                                              # 40 spheres in a row along -z
+        mat = pt.Metal.new((0.8, 0.7, 0.6), 0.1) if k % 3 == 0 else (pt.Dielectric.new(1.5) if k % 3 == 1 else pt.Lambertian.new_solid((0.2, 0.4, 0.8)))
+        scene.add(pt.Sphere.new((0.05 * (k % 5), 0.0, -float(k)), 0.3, mat))
+    scene.add(pt.Sphere.new((0.0, 0.0, 0.5), 1.5, pt.Dielectric.new(1.5)))        # around the first eye
+    scene.add(pt.Sphere.new((0.0, 0.0, 6.0), 1.0, pt.Lambertian.new_solid((0.9, 0.1, 0.1))))   # behind it
+    for _ in range(2):                                                  # exact duplicates: ties in t
+        scene.add(pt.Sphere.new((1.5, 0.0, -4.0), 0.5, pt.Lambertian.new_solid((0.1, 0.9, 0.1))))
+    renderer.set_lanes_per_pixel(1)
+    try:
+        for eye, target in (((0.0, 0.0, 0.5), (0.0, 0.0, -10.0)), ((0.02, 0.1, 1.0), (0.1, 0.0, -20.0)),
+                            ((6.0, 1.0, -20.0), (0.0, 0.0, -20.0)), ((0.0, 30.0, -20.0), (0.0, 0.0, -20.5))):
+            cam = pt.Camera.new(eye, target, (0.0, 1.0, 0.0), 40.0, 96, 56)
+            rt = pt.Raytracer.new(cam, scene, 3)
+            osc = oracle.OracleScene(rt.packed)
+            ref = osc.render(cam.pod, 3, seed=4, hit_ids=True)
+            img, rad, ids = renderer.render(rt, seed=4, radiance=True, hit_ids=True)
+            assert renderer.primary_lists()
+            assert np.array_equal(ids, ref["hit_id"])
+            assert same_bits(rad, ref["radiance"]), "eye %s: %d words differ" % (eye, np.sum(rad.view(np.uint32) != ref["radiance"].view(np.uint32)))
+    finally:
+        renderer.set_lanes_per_pixel(0)
+
+
+@pytest.mark.gpu
+def test_primary_lists_are_off_where_boxes_do_not_contain_their_spheres(renderer, oracle):
+    """A tree with a box that does not contain its sphere (negative radius: sphere.rs:71-76) keeps the plain walk for
+    camera rays too: there a box test can change the closest hit, so none may be skipped."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    pt.random_scene(scene, 77, (-3, 3, -3, 3))
+    scene.add(pt.Sphere.new((0.0, 1.0, 0.0), -0.9, pt.Dielectric.new(1.5)))
+    cam = pt.Camera.new(width=96, height=54, **MAIN_RS_CAMERA)
+    rt = pt.Raytracer.new(cam, scene, 3)
+    osc = oracle.OracleScene(rt.packed)
+    renderer.set_lanes_per_pixel(1)
+    try:
+        img, rad, _ = renderer.render(rt, seed=2, radiance=True)
+        assert not renderer.primary_lists() and renderer.walk_order() == 0
+        assert same_bits(rad, osc.render(cam.pod, 3, seed=2)["radiance"])
+    finally:
+        renderer.set_lanes_per_pixel(0)

@@ -41,5 +41,17 @@ for static in (True, False):
     g2.replay(); torch.cuda.synchronize()
     a = accum.cpu().numpy()
     print("  path graph replay 2: nan words", int(np.isnan(a).sum()), "equal", np.array_equal(a.view(np.uint32), rad_ref.reshape(-1).view(np.uint32)), flush=True)
-    del g, g2
+    # 3. path + resolve in one graph (the test's shape)
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3, stream=side, capture_error_mode="thread_local"):
+        cap = torch.cuda.current_stream(dev).cuda_stream
+        r.render_device(rt, accum.data_ptr(), seed=21, stream=cap, static_scratch=static)
+        r.resolve_device(rt, accum.data_ptr(), rgb8.data_ptr(), stream=cap)
+    for k in range(2):
+        accum.fill_(float("nan")); rgb8.zero_(); torch.cuda.synchronize()
+        g3.replay(); torch.cuda.synchronize()
+        a = accum.cpu().numpy()
+        print("  path+resolve graph replay", k, ": nan words", int(np.isnan(a).sum()), "equal", np.array_equal(a.view(np.uint32), rad_ref.reshape(-1).view(np.uint32)),
+              "image ok", np.array_equal(rgb8.cpu().numpy().reshape(img_ref.shape), img_ref), flush=True)
+    del g, g2, g3
 r.close()
