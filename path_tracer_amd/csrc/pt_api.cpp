@@ -80,8 +80,14 @@ int check_kernel_error(pt_context *c)
 #endif
     int32_t ctrl[2] = {0, 0};
     PT_HIP(c, hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost));
-    if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
-    if (ctrl[1] != 0) return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
+    if (ctrl[1] != 0) {
+        // a launch that reported an error may have left its words in any state: the whole scratch is cleared
+        // (the launch is complete, and its stream idle, when this runs)
+        const size_t bytes = c->last_sched == c->static_sched ? c->static_sched_bytes : c->sched_bytes;
+        (void)hipMemset(c->last_sched, 0, bytes);
+        if (ctrl[1] == 2) return fail(c, PT_ERR_HIP, "path kernel: dynamic LDS does not start at address 0");
+        return fail(c, PT_ERR_HIP, "path kernel: a piece gave up waiting for its predecessor");
+    }
     return PT_OK;
 }
 
@@ -778,6 +784,10 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
         PT_HIP(c, hipSetDevice(c->device));
         int32_t *fresh = nullptr;
         PT_HIP(c, hipMalloc((void **)&fresh, need));
+        if (hipMemset(fresh, 0, need) != hipSuccess) {     // a launch expects its words at zero and leaves them so (pt_kernels.hip retire_group)
+            (void)hipFree(fresh);
+            return fail(c, PT_ERR_HIP, "hipMemset of the work-distribution scratch failed");
+        }
         // launches on caller streams (pt_render_device) may still be using the old scratch
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) {
@@ -1171,6 +1181,7 @@ float pt_last_path_kernel_ms(pt_context *c)
 #endif
     int32_t ctrl[2] = {0, 0};
     if (c->last_sched && hipMemcpy(ctrl, c->last_sched, sizeof ctrl, hipMemcpyDeviceToHost) == hipSuccess && ctrl[1] != 0) {
+        (void)hipMemset(c->last_sched, 0, c->last_sched == c->static_sched ? c->static_sched_bytes : c->sched_bytes);
         (void)fail(c, PT_ERR_HIP, ctrl[1] == 2 ? "path kernel: dynamic LDS does not start at address 0"
                                                : "path kernel: a piece gave up waiting for its predecessor");
         return -2.0f;

@@ -687,6 +687,31 @@ static size_t group_lds_bytes(const Scene &sc, int n1off)
     return (size_t)n1off + ((size_t)sc.lds_nodes + 1) * sizeof(float4) + (sc.ext ? 2 * (size_t)sc.lds_xforms * sizeof(float4) : 0);
 }
 
+// The launch's work-distribution words clean up after themselves: a launch needs the ticket counter and the tiles'
+// `done` words at zero, and instead of a memset in front of every launch (one more operation on the stream -- and one
+// more node for a HIP graph to order) the LAST workgroup to finish puts them back.  Every workgroup counts itself
+// out in ctrl[2] once all its waves are through; whoever brings the count to gridDim.x knows that no wave of the
+// launch will read a word again.  The error word ctrl[1] is left alone (the host reads and clears it).  The words
+// start at zero: the library's static array is zero-initialised, a context's own scratch is cleared when allocated.
+__device__ __forceinline__ void retire_group(const SchedParams &sched)
+{
+    // (no static __shared__ in these kernels -- the staged nodes must start at LDS address 0 -- so the flag
+    // takes the first word of the staged copy, which nobody reads after the barrier)
+    extern __shared__ float4 lds_n0[];
+    int &last = *(int *)&lds_n0[0];
+    __syncthreads();                                                             // all waves of the group are through their items
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&sched.ctrl[2], 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (sched.n_pieces > 1)
+        for (int i = threadIdx.x; i < sched.n_tiles; i += blockDim.x) sched.done[i] = 0;
+    if (threadIdx.x == 0) { sched.ctrl[0] = 0; sched.ctrl[2] = 0; }
+}
+
 // The launch without the item loop: one workgroup of 4 waves per 4 items.  It serves the scenes of a handful of
 // primitives only (launch_path).
 template <bool EXT = false>
@@ -705,8 +730,8 @@ __global__ __launch_bounds__(256, PT_MIN_WAVES) void path_kernel(Scene sc, Camer
     __syncthreads();
     const int n_items = sched.n_tiles * sched.n_pieces;
     const int item = __builtin_amdgcn_readfirstlane(ticket) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (item >= n_items) return;
-    render_item<true, EXT, PT_SMALL_N1_OFFSET>(sc, cam, rp, sched, radiance, item, xf_lds);
+    if (item < n_items) render_item<true, EXT, PT_SMALL_N1_OFFSET>(sc, cam, rp, sched, radiance, item, xf_lds);
+    retire_group(sched);
 }
 
 // The persistent launch: as many workgroups as the chip holds, each wave drawing items until none are left.  The
@@ -757,11 +782,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         t_draw += t1 - t0;
 #endif
         if (item >= n_items) break;
+#if defined(PT_INLINE_ITEM) && __HIP_DEVICE_COMPILE__
+        {   // the item's body in the loop, its arguments re-read through a pointer the compiler cannot see through
+            uint64_t addr = args;
+            asm volatile("" : "+s"(addr));
+            const PathArgsPtr pa = (PathArgsPtr)addr;
+            const Scene sc = pa->sc;
+            const Camera cam = pa->cam;
+            const RenderParams rp = pa->rp;
+            const SchedParams sched = pa->sched;
+            render_item<ALL_IN_LDS, EXT, PT_LDS_N1_OFFSET>(sc, cam, rp, sched, pa->radiance, item, xf_lds);
+        }
+#elif !defined(PT_INLINE_ITEM)
         render_item_call<ALL_IN_LDS, EXT>((uint32_t)args, (uint32_t)(args >> 32), item, xf_lds);
+#endif
 #ifdef PT_PHASES
         t_item += clock64() - t1;
 #endif
     }
+    retire_group(a.sched);
 #ifdef PT_PHASES
     if ((threadIdx.x & 63) == 0) {
         atomicAdd((unsigned long long *)&a.sched.ctrl[16], t_draw);
@@ -1145,8 +1184,11 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     sp.piece_len = (count + pieces - 1) / pieces;
     sp.n_pieces = sp.piece_len > 0 ? (count + sp.piece_len - 1) / sp.piece_len : 1;
     if (sp.n_pieces < 1) sp.n_pieces = 1;
+#ifdef PT_PHASES   // the measurement build sums cycles in the control words: cleared per launch
     hipError_t e = hipMemsetAsync(d_sched, 0, sched_bytes(cam), stream);
     if (e != hipSuccess) return e;
+#endif
+    // (no memset: the previous launch left the words at zero -- retire_group)
     const long long items = (long long)sp.n_tiles * sp.n_pieces;
     const bool in_lds = sc.lds_nodes >= sc.n_nodes;
     // A scene of a handful of primitives keeps the launch of one workgroup of 4 waves per 4 items: its paths are a
