@@ -782,20 +782,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         t_draw += t1 - t0;
 #endif
         if (item >= n_items) break;
-#if defined(PT_INLINE_ITEM) && __HIP_DEVICE_COMPILE__
-        {   // the item's body in the loop, its arguments re-read through a pointer the compiler cannot see through
-            uint64_t addr = args;
-            asm volatile("" : "+s"(addr));
-            const PathArgsPtr pa = (PathArgsPtr)addr;
-            const Scene sc = pa->sc;
-            const Camera cam = pa->cam;
-            const RenderParams rp = pa->rp;
-            const SchedParams sched = pa->sched;
-            render_item<ALL_IN_LDS, EXT, PT_LDS_N1_OFFSET>(sc, cam, rp, sched, pa->radiance, item, xf_lds);
-        }
-#elif !defined(PT_INLINE_ITEM)
         render_item_call<ALL_IN_LDS, EXT>((uint32_t)args, (uint32_t)(args >> 32), item, xf_lds);
-#endif
 #ifdef PT_PHASES
         t_item += clock64() - t1;
 #endif

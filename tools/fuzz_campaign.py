@@ -24,6 +24,7 @@ r = pt.ParallelRenderer.new(0)
 bad = []
 paths = 0
 view_order = 0        # cases the library walked nearer-child-first (PT_WALK_VIEW in effect)
+with_lists = 0        # cases whose camera rays tested candidate lists instead of walking (pt_get_primary_lists)
 t0 = time.time()
 for k in range(first, last):
     rt, samples = _fuzz_case(k)
@@ -33,6 +34,7 @@ for k in range(first, last):
     img, rad, ids = r.render(rt, seed=k, radiance=True, hit_ids=True)
     r.set_lanes_per_pixel(0)
     view_order += r.walk_order()
+    with_lists += int(r.primary_lists())
     ok = np.array_equal(ids, ref["hit_id"]) and np.array_equal(rad.view(np.uint32), ref["radiance"].view(np.uint32))
     r.bind(rt)
     lanes = r.lanes_per_pixel(samples, 0, samples * samples)
@@ -47,7 +49,7 @@ for k in range(first, last):
     if k % 50 == 0:
         print("case %d, %d mismatching so far, %.0f s" % (k, len(bad), time.time() - t0), flush=True)
 out = {"cases": last - first, "first": first, "last": last, "paths": int(paths), "mismatching_cases": bad,
-       "cases_walked_in_view_order": int(view_order)}
+       "cases_walked_in_view_order": int(view_order), "cases_with_primary_lists": int(with_lists)}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_campaign.json"), "w"))
