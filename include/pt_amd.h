@@ -169,12 +169,13 @@ int pt_primary_hits_device(pt_context *ctx, int32_t samples, int32_t sample_inde
  *           this context or of any other context of the GPU -- while the array's previous launch has
  *           not completed returns PT_ERR_INVALID instead of racing (launches on ONE stream are
  *           ordered and fine).  GPUs beyond the 64th of a process are not tracked.
- *   capture: on a stream under HIP graph capture the call records a memset node and a kernel node and
- *           nothing else (no events, no in-flight check: ordering is the graph's business; the occupancy
- *           and attribute queries of the launch are cached from the first un-captured launch of the same
- *           scene size).  pt_last_path_kernel_ms returns -1 for such a launch.  tests/test_zz_no_alloc.py
- *           captures pt_render_device_static + pt_resolve_device, replays the graph twice and compares
- *           with pt_render bit for bit. */
+ *   capture: on a stream under HIP graph capture the call records ONE kernel node and nothing else (no
+ *           memset: a launch leaves its work-distribution words at zero for the next one; no events, no
+ *           in-flight check: ordering is the graph's business; the occupancy and attribute queries of the
+ *           launch are cached from the first un-captured launch of the same scene size).
+ *           pt_last_path_kernel_ms returns -1 for such a launch.  tests/test_zz_no_alloc.py captures
+ *           pt_render_device_static + pt_resolve_device, replays the graph twice and compares with
+ *           pt_render bit for bit. */
 int pt_render_device_static(pt_context *ctx, int32_t samples, uint64_t seed, int32_t sample_begin,
                             int32_t sample_end, int32_t accumulate, float *d_radiance, void *stream);
 
@@ -262,6 +263,12 @@ int pt_get_primary_lists(const pt_context *ctx);
  * clock is the chip's choice under load -- bench.py calls this right before and right after its timed
  * region so that a slower box can be told from a slower kernel.  Blocking; allocates. */
 int pt_clock_probe(pt_context *ctx, float *ghz);
+
+/* The shader clock the most recent persistent path-kernel launch of the context ran at, in GHz: its first workgroup
+ * stamps the shader-cycle counter and the constant 100 MHz counter once at its start and once at its end (two stamps per
+ * launch, none inside the work).  Synchronises the launch's stream.  -1: no launch yet, a captured launch, or the
+ * small-tree launch (scenes of fewer than 32 nodes), which does not stamp.  No counterpart in the reference. */
+float pt_last_path_kernel_clock_ghz(pt_context *ctx);
 
 /* How a pixel's samples are spread over GPU lanes.  0 (default) = automatic:
  * one lane owns all samples of a pixel whenever the frame alone fills the GPU,

@@ -110,6 +110,7 @@ extern "C" {
     pub fn pt_get_walk_order(ctx: *const pt_context) -> c_int;
     pub fn pt_set_primary_lists(ctx: *mut pt_context, enabled: i32) -> c_int;
     pub fn pt_get_primary_lists(ctx: *const pt_context) -> c_int;
+    pub fn pt_last_path_kernel_clock_ghz(ctx: *mut pt_context) -> f32;
     pub fn pt_clock_probe(ctx: *mut pt_context, ghz: *mut f32) -> c_int;
     pub fn pt_set_lanes_per_pixel(ctx: *mut pt_context, lanes: i32) -> c_int;
     pub fn pt_get_lanes_per_pixel(ctx: *const pt_context, samples: i32, sample_begin: i32, sample_end: i32) -> c_int;

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pt_get_walk_order": (C.c_int, [C.c_void_p]),
     "pt_set_primary_lists": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_primary_lists": (C.c_int, [C.c_void_p]),
+    "pt_last_path_kernel_clock_ghz": (C.c_float, [C.c_void_p]),
     "pt_clock_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pt_set_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_lanes_per_pixel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -342,7 +342,12 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
   // whole tile x all samples per wave left the chip at 4.75 of 8 waves per SIMD on average:
   // profiles/r01/v2); a loop over items inside the wave cost 4-20 % in code quality.
   {
-    const int piece = item / sched.n_tiles, tile = item - piece * sched.n_tiles;
+    const int piece = item / sched.n_tiles, tile_at = item - piece * sched.n_tiles;
+#ifndef PT_NO_TILE_ORDER   // (measurement builds: row-major)
+    const int tile = (rp.lanes == 1 && sc.tile_order) ? sc.tile_order[tile_at] : tile_at;   // whole-tile lanes: a tile is a pixel block
+#else
+    const int tile = tile_at;
+#endif
     const int ps0 = rp.s0 + piece * sched.piece_len;
     const int ps1 = ps0 + sched.piece_len < rp.s1 ? ps0 + sched.piece_len : rp.s1;
     const int px = (tile % tiles_x) * tw + slot % tw;
@@ -763,6 +768,12 @@ template <bool ALL_IN_LDS, bool EXT = false>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel_persistent(PathArgs a)
 {
     uint32_t xf_lds; int ticket_slot;
+    // The launch's own clock, for the bench record: workgroup 0 lives as long as the launch does, and its first wave
+    // stamps the shader-cycle counter and the constant 100 MHz counter ONCE at its start and once at its end (two stamps
+    // per launch; no stamp executes inside an item).  The four words they go to are read by the host only.
+    const bool stamper = blockIdx.x == 0 && threadIdx.x < 64;
+    unsigned long long clk0 = 0, ref0 = 0;
+    if (stamper) { clk0 = __builtin_amdgcn_s_memtime(); ref0 = __builtin_amdgcn_s_memrealtime(); }
     if (!stage_group<EXT, PT_LDS_N1_OFFSET>(a.sc, a.sched, xf_lds, ticket_slot)) return;
     __syncthreads();
     const int n_items = a.sched.n_tiles * a.sched.n_pieces;
@@ -786,6 +797,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
 #ifdef PT_PHASES
         t_item += clock64() - t1;
 #endif
+    }
+    if (stamper && threadIdx.x == 0) {
+        const unsigned long long clk = __builtin_amdgcn_s_memtime() - clk0, ref = __builtin_amdgcn_s_memrealtime() - ref0;
+        a.sched.ctrl[4] = (int32_t)(uint32_t)clk; a.sched.ctrl[5] = (int32_t)(uint32_t)(clk >> 32);
+        a.sched.ctrl[6] = (int32_t)(uint32_t)ref; a.sched.ctrl[7] = (int32_t)(uint32_t)(ref >> 32);
     }
     retire_group(a.sched);
 #ifdef PT_PHASES
@@ -1145,8 +1161,10 @@ int tiles_for(const Camera &cam, int lanes)
 }
 
 // control words + one `done` word per 8x8 tile (the only tiling that is split into pieces)
+bool launch_is_persistent(const Scene &sc) { return sc.ext || sc.n_nodes >= PT_SMALL_TREE; }
 size_t sched_bytes(const Camera &cam) { return (64 + (size_t)tiles_for(cam, 1)) * sizeof(int32_t); }
 #else
+using ptk::launch_is_persistent;
 using ptk::sched_bytes;
 using ptk::tiles_for;
 #endif   // !PT_FAST_MODE
@@ -1183,7 +1201,7 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     // the cheap tiles, and the waves that draw the next pieces of the dear ones stand waiting for their predecessors
     // (cfg 2, 1920x1080 @ 256 spp: 12.5 ms this way, 17.5 ms with the persistent launch, 11 % of whose wave time is
     // that wait -- 11.0 against 14.7 ms since pieces are 64 samples; the headline frame waits 0.02 % of its time).
-    if (!sc.ext && sc.n_nodes < PT_SMALL_TREE) {
+    if (!launch_is_persistent(sc)) {
         const dim3 grid((unsigned)((items + 3) / 4)), block(256);
         hipLaunchKernelGGL((path_kernel<false>), grid, block, group_lds_bytes(sc, PT_SMALL_N1_OFFSET), stream, sc, cam, rp, sp, d_radiance);
         return hipGetLastError();

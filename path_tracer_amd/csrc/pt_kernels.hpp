@@ -52,6 +52,8 @@ hipError_t launch_grid_selftest(int width, int height, int S, float inv_s1, floa
 hipError_t launch_path(const ptd::Scene &sc, const ptd::Camera &cam, const RenderParams &rp, int32_t *d_sched,
                        float *d_radiance, hipStream_t stream);
 size_t sched_bytes(const ptd::Camera &cam);
+// does launch_path render this scene with the persistent kernel (which stamps its clock) or with the small-tree one?
+bool launch_is_persistent(const ptd::Scene &sc);
 // address and size of the library's file-scope scratch array on the current device (pt_render_device_static)
 hipError_t static_sched(int device, int32_t **out, size_t *bytes);
 // the array's in-flight record, shared by every context of the device: *busy = its previous launch went to another

@@ -164,6 +164,10 @@ class ParallelRenderer:
             _abi.check(self._ctx, -2)        # PT_ERR_HIP with the kernel's message
         return ms
 
+    def last_path_kernel_clock_ghz(self):
+        """pt_last_path_kernel_clock_ghz: the clock the last persistent path-kernel launch ran at (-1: none / small-tree launch)"""
+        return float(_abi.lib().pt_last_path_kernel_clock_ghz(self._ctx))
+
     def clock_probe(self):
         """pt_clock_probe: the GPU's shader clock right now, in GHz (a 2 ms chip-filling multiply chain)."""
         ghz = C.c_float(0.0)
@@ -286,6 +290,9 @@ class RendererGroup:
     def inject_fault(self, rank, kind):
         """pt_group_inject_fault (test hook, host side only)"""
         self._check(_abi.lib().pt_group_inject_fault(self._grp, int(rank), int(kind)))
+
+    def last_path_kernel_clock_ghz(self, rank=0):
+        return float(_abi.lib().pt_last_path_kernel_clock_ghz(self.context(rank)))
 
     def clock_probe(self, rank=0):
         ghz = C.c_float(0.0)

@@ -204,6 +204,12 @@ def test_group_wait_reports_a_failed_or_late_gpu_instead_of_hanging(oracle):
 def test_clock_probe_reads_a_plausible_shader_clock(renderer):
     ghz = renderer.clock_probe()
     assert 0.8 < ghz < 2.6, ghz            # MI355X: up to 2.4 GHz, lower under load
+    rt = make_raytracer("rtow", 640, 360, 8)
+    renderer.render(rt, seed=1)
+    ghz = renderer.last_path_kernel_clock_ghz()      # the persistent launch's own two stamps
+    assert 0.8 < ghz < 2.6, ghz
+    renderer.render(make_raytracer("simple", 64, 36, 2), seed=1)
+    assert renderer.last_path_kernel_clock_ghz() == -1.0   # the small-tree launch does not stamp
 
 
 def test_stream_ordered_render_reduce_resolve_equals_render(renderer, oracle):
