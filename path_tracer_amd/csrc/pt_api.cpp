@@ -367,7 +367,6 @@ int build_primary_lists(pt_context *c)
 {
     c->scene.cand = nullptr;
     c->scene.cand_tiles_x = 0;
-    c->scene.tile_order = nullptr;
     if (!c->have_scene || !c->have_camera || !c->primary_lists || !c->view_ok || c->scene.ext || !c->threaded) return PT_OK;
     // the small-tree launch keeps the plain walk (pt_kernels.hip launch_path), and so does a scene x frame whose
     // brute-force list build would take longer than it saves (a lane per block tests every sphere)
@@ -392,44 +391,11 @@ int build_primary_lists(pt_context *c)
         PT_HIP(c, hipDeviceSynchronize());
         PT_HIP(c, ptk::launch_primary_lists(c->scene, c->camera, c->d_leaf_codes, c->scene.n_spheres, c->d_lists, c->stream));
         PT_HIP(c, hipStreamSynchronize(c->stream));
-        // The order in which a launch hands out the tiles of each piece: what a tile costs grows with what its camera
-        // rays can hit, so the blocks with the most candidates go first and the empty ones (sky) last -- a launch then
-        // ends on its cheapest items instead of on whatever the last rows of the frame hold.  Scheduling only: every
-        // item is rendered whatever the order, and piece k of a tile still holds a higher ticket than piece k - 1.
-        std::vector<int32_t> lists, order;
-        try {
-            lists.resize((size_t)blocks * PT_PRIMARY_K);
-            order.resize((size_t)blocks);
-        } catch (...) {
-            return fail(c, PT_ERR_INVALID, "out of host memory");
-        }
-        PT_HIP(c, hipMemcpy(lists.data(), c->d_lists, need, hipMemcpyDeviceToHost));
-        size_t start[PT_PRIMARY_K + 2] = {0};
-        auto weight = [&](int64_t b) -> int {          // 0 .. K candidates; K + 1 = "too many, walks the tree"
-            const int32_t *row = lists.data() + (size_t)b * PT_PRIMARY_K;
-            if (row[0] == 1) return PT_PRIMARY_K + 1;
-            int k = 0;
-            while (k < PT_PRIMARY_K && row[k] != 0) k++;
-            return k;
-        };
-        for (int64_t b = 0; b < blocks; b++) start[PT_PRIMARY_K + 1 - weight(b)]++;       // bucket 0 = heaviest
-        size_t at = 0;
-        for (int k = 0; k < PT_PRIMARY_K + 2; k++) { const size_t n = start[k]; start[k] = at; at += n; }
-        for (int64_t b = 0; b < blocks; b++) order[start[PT_PRIMARY_K + 1 - weight(b)]++] = (int32_t)b;
-        if (need / PT_PRIMARY_K > c->tile_order_bytes) {
-            int32_t *fresh = nullptr;
-            PT_HIP(c, hipMalloc((void **)&fresh, need / PT_PRIMARY_K));
-            if (c->d_tile_order) (void)hipFree(c->d_tile_order);     // the device is idle (synchronised above)
-            c->d_tile_order = fresh;
-            c->tile_order_bytes = need / PT_PRIMARY_K;
-        }
-        PT_HIP(c, hipMemcpy(c->d_tile_order, order.data(), (size_t)blocks * sizeof(int32_t), hipMemcpyHostToDevice));
         c->lists_camera = c->camera;
         c->lists_valid = true;
     }
     c->scene.cand = c->d_lists;
     c->scene.cand_tiles_x = (c->camera.width + 7) / 8;
-    c->scene.tile_order = c->d_tile_order;
     return PT_OK;
 }
 
@@ -499,7 +465,6 @@ void pt_destroy(pt_context *c)
     free_frame(c);
     if (c->d_sched) (void)hipFree(c->d_sched);
     if (c->d_lists) (void)hipFree(c->d_lists);
-    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->ev_own_done) (void)hipEventDestroy(c->ev_own_done);
@@ -711,7 +676,6 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     c->scene.n_nodes = n_slots;              // slots, not nodes: the code 16 * n_slots ends a walk and bounds the arrays
     c->scene.cand = nullptr;
     c->scene.cand_tiles_x = 0;
-    c->scene.tile_order = nullptr;
     c->lists_valid = false;
     c->scene.n_spheres = n_prims;
     c->scene.lds_nodes = n_nodes < kMaxLdsNodes ? n_nodes : kMaxLdsNodes;
@@ -849,8 +813,7 @@ int pt_set_camera(pt_context *c, const pt_camera *cam)
             c->camera = previous;
             c->have_camera = had_camera;
             c->scene.cand = nullptr;             // lists of another camera are never used: the plain walk until the next success
-            c->scene.tile_order = nullptr;
-            c->lists_valid = false;
+                    c->lists_valid = false;
             return rc;
         }
     }

@@ -57,8 +57,6 @@ struct pt_context {
     bool lists_valid = false;            // d_lists was built for lists_camera and the current node codes
     ptd::Camera lists_camera{};
     bool primary_lists = true;           // pt_set_primary_lists
-    int32_t *d_tile_order = nullptr;     // per piece: the blocks in the order they are handed out (most candidates first)
-    size_t tile_order_bytes = 0;
 
     int32_t *d_sched = nullptr;   // work counter, error flag, per-tile progress (pt_kernels.hpp SchedParams)
     size_t sched_bytes = 0;

@@ -39,9 +39,6 @@ struct Scene {
     // ended by 0; a first entry of 1 = too many: walk the tree.  cand_tiles_x = blocks per row.
     const int32_t *cand;
     int32_t cand_tiles_x;
-    // the order in which a launch hands out the 8x8 tiles of each piece, or NULL (row-major): the blocks with the most
-    // candidates first, the empty (sky) ones last, so that a launch ends on its cheapest items (pt_api.cpp build_primary_lists)
-    const int32_t *tile_order;
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;

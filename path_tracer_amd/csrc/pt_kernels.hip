@@ -342,12 +342,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
   // whole tile x all samples per wave left the chip at 4.75 of 8 waves per SIMD on average:
   // profiles/r01/v2); a loop over items inside the wave cost 4-20 % in code quality.
   {
-    const int piece = item / sched.n_tiles, tile_at = item - piece * sched.n_tiles;
-#ifndef PT_NO_TILE_ORDER   // (measurement builds: row-major)
-    const int tile = (rp.lanes == 1 && sc.tile_order) ? sc.tile_order[tile_at] : tile_at;   // whole-tile lanes: a tile is a pixel block
-#else
-    const int tile = tile_at;
-#endif
+    const int piece = item / sched.n_tiles, tile = item - piece * sched.n_tiles;
     const int ps0 = rp.s0 + piece * sched.piece_len;
     const int ps1 = ps0 + sched.piece_len < rp.s1 ? ps0 + sched.piece_len : rp.s1;
     const int px = (tile % tiles_x) * tw + slot % tw;
