@@ -28,6 +28,8 @@ constexpr int32_t kMaxLdsNodes = PT_MAX_LDS_NODES;   // both halves of these nod
 // slots 0 .. kMaxLdsNodes-1 and the others from PT_FIRST_GLOBAL_SLOT on (the slots between are never used), so that a
 // byte offset below PT_LDS_N1_OFFSET always means LDS.
 int32_t slots_for(int32_t n_nodes) { return n_nodes <= kMaxLdsNodes ? n_nodes : PT_FIRST_GLOBAL_SLOT + (n_nodes - kMaxLdsNodes); }
+// 16 * end_slot_for(n) is the code that ends a walk: above every node's code and above the chain entries' LDS offsets
+int32_t end_slot_for(int32_t n_nodes) { return std::max(slots_for(n_nodes), (int32_t)PT_FIRST_GLOBAL_SLOT); }
 
 }  // namespace
 
@@ -197,7 +199,7 @@ int thread_nodes(pt_context *c)
     const float eye[3] = {c->camera.origin.x, c->camera.origin.y, c->camera.origin.z};
     if (c->threaded && c->threaded_view == view && (!view || std::memcmp(eye, c->threaded_eye, sizeof eye) == 0)) return PT_OK;
 
-    std::vector<int32_t> slot, order, first, second, succ, walk, stack, leaf_codes;
+    std::vector<int32_t> slot, order, first, second, succ, walk, stack, leaf_codes, parent;
     std::vector<float4> h_nodes;
     const int32_t n_slots = slots_for(n_nodes);
     try {
@@ -209,7 +211,8 @@ int thread_nodes(pt_context *c)
         walk.reserve((size_t)n_nodes);
         stack.reserve(64);
         h_nodes.assign(2 * (size_t)slots_for(n_nodes), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        leaf_codes.assign((size_t)c->scene.n_spheres, 0);
+        leaf_codes.assign(2 * (size_t)c->scene.n_spheres, 0);   // [rank] the Leaf's code, [n + rank] its parent Split's
+        parent.assign((size_t)n_nodes, 0);
     } catch (...) {
         return fail(c, PT_ERR_INVALID, "out of host memory");
     }
@@ -232,6 +235,8 @@ int thread_nodes(pt_context *c)
         const bool swap = view && dist2(r) < dist2(l);   // NaN compares false: left first
         first[i] = swap ? r : l;
         second[i] = swap ? l : r;
+        parent[(size_t)l] = i;
+        parent[(size_t)r] = i;
     }
     // walk order (depth-first, first child before second) and every node's successor
     try {
@@ -314,7 +319,7 @@ int thread_nodes(pt_context *c)
     }
     // node code: slot with the sign bit set for a Leaf; n_nodes ends the walk
     auto code_of = [&](int32_t i) -> int32_t {
-        if (i >= n_nodes) return n_slots << PT_CODE_SHIFT;
+        if (i >= n_nodes) return end_slot_for(n_nodes) << PT_CODE_SHIFT;
         return nodes[i].prim >= 0 ? (int32_t)((uint32_t)(slot[i] << PT_CODE_SHIFT) | 0x80000000u) : (slot[i] << PT_CODE_SHIFT);
     };
     float4 *h_n0 = h_nodes.data(), *h_n1 = h_nodes.data() + n_slots;
@@ -335,6 +340,7 @@ int thread_nodes(pt_context *c)
             int32_t rank;
             std::memcpy(&rank, &b.z, 4);
             leaf_codes[(size_t)rank] = code_of(i);      // rank: validated at upload, one Leaf per primitive
+            leaf_codes[(size_t)c->scene.n_spheres + (size_t)rank] = code_of(parent[(size_t)i]);   // (a lone Leaf: the root itself; no lists then)
         }
         h_n0[slot[i]] = a;
         h_n1[slot[i]] = b;
@@ -635,7 +641,7 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     free_scene(c);
     const int32_t n_slots = slots_for(n_nodes);
     PT_HIP(c, hipMalloc((void **)&c->d_nodes, 2 * (size_t)n_slots * sizeof(float4)));
-    PT_HIP(c, hipMalloc((void **)&c->d_leaf_codes, (size_t)n_prims * sizeof(int32_t)));
+    PT_HIP(c, hipMalloc((void **)&c->d_leaf_codes, 2 * (size_t)n_prims * sizeof(int32_t)));
     PT_HIP(c, hipMalloc((void **)&c->d_prims, h_prims.size() * sizeof(float4)));
     PT_HIP(c, hipMemcpy(c->d_prims, h_prims.data(), h_prims.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMalloc((void **)&c->d_prim_ids, prim_ids.size() * sizeof(int32_t)));
@@ -673,7 +679,9 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     c->scene.xforms = c->d_xforms;
     c->scene.ext = ext ? 1 : 0;
     c->scene.lds_xforms = (ext && n_xforms <= 128) ? n_xforms : 0;   // 4 KiB of LDS at most; more: read through the L1
-    c->scene.n_nodes = n_slots;              // slots, not nodes: the code 16 * n_slots ends a walk and bounds the arrays
+    c->scene.n_nodes = n_slots;              // slots, not nodes: bounds the arrays
+    c->scene.end_slot = end_slot_for(n_nodes);
+    c->scene.parent_codes = c->d_leaf_codes + n_prims;
     c->scene.cand = nullptr;
     c->scene.cand_tiles_x = 0;
     c->lists_valid = false;

@@ -26,7 +26,9 @@ struct Scene {
     const float4 *prims;
     const int32_t *prim_ids;
     const Texture *textures;
-    int32_t n_nodes, n_spheres;
+    int32_t n_nodes, n_spheres;   // n_nodes: slots of the node arrays
+    int32_t end_slot;        // 16 * end_slot is the code that ends a walk: max(n_nodes, PT_FIRST_GLOBAL_SLOT), above every node's
+                             // code and above the LDS offsets of the waves' chain entries, which are Split codes too
     int32_t root_code;       // node code of the root
     int32_t lds_nodes;       // n0[0 .. lds_nodes) is staged in LDS by the path kernel
     int32_t bounded;         // every sphere has |c_i| <= 2^32 and |r| <= 2^32 (see regular_ray)
@@ -39,6 +41,7 @@ struct Scene {
     // ended by 0; a first entry of 1 = too many: walk the tree.  cand_tiles_x = blocks per row.
     const int32_t *cand;
     int32_t cand_tiles_x;
+    const int32_t *parent_codes;   // per primitive rank: the code of its Leaf's parent Split
 };
 struct Camera {               // camera.rs:4-11
     f3 llc, origin, horizontal, vertical;
@@ -582,7 +585,7 @@ PTD Hit scene_trace(const Scene &sc, const Ray &ray)
     const float ra = rcp_core(a);                                                // read by REGULAR rays only
     Hit h; h.t = T_MAX; h.prim = -1;
     int32_t code = sc.root_code;
-    while (code_index(code) < sc.n_nodes) {   // code_index(end code) == n_nodes
+    while (code_index(code) < sc.end_slot) {   // code_index(end code) == end_slot
         const int i = code_index(code);
         const float4 n0 = sc.n0[i], n1 = sc.n1[i];
         if (code < 0) {
@@ -641,11 +644,9 @@ PTD bool scatter_at(const Scene &sc, const Ray &ray, const f3 p, const f3 n, con
     out.o = p; out.d = normalized(nd);                                           // ray.rs:19-24 (discarded when absorbed)
     return alive;
 }
-// Sphere::record (sphere.rs:37-42) + scatter for a hit sphere
-PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
+// Sphere::record (sphere.rs:37-42) + scatter for a hit sphere whose 32-byte record is (sp, ma)
+PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, const float4 sp, const float4 ma, uint64_t &rng, f3 &att, Ray &out)
 {
-    const float4 sp = sc.prims[2 * h.prim];
-    const float4 ma = sc.prims[2 * h.prim + 1];
     const int2 mb = make_int2(__float_as_int(sp.w) & 3, (__float_as_int(sp.w) >> 2) - 1);   // (kind, texture or -1)
     const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
     const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));

@@ -79,6 +79,14 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #ifndef PT_ITEMS_PER_SLOT
 #define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
 #endif
+#ifndef PT_PARK_MIN
+// A Dielectric's scatter (refract + schlick + a draw: ~60 vector instructions) and a picture texture's lookup (fp64 atan2 /
+// asin: ~300) run for the whole wave whenever ONE lane of a SHADE step needs them -- and on the bench scenes one or two
+// of a step's ~32 hit lanes do, in four steps of five.  Lanes whose hit needs either are PARKED (their own state code)
+// until PT_PARK_MIN of them wait, or no lane of the wave has a walk to go on with; then one step serves them all.  Each
+// lane still runs exactly its own operations on its own stream: only WHEN differs.  0 = never park.
+#define PT_PARK_MIN 0
+#endif
 #ifndef PT_LEAF_KEEP
 #define PT_LEAF_KEEP 2    // the same for a LEAF run (a Leaf's next node is often its sibling Leaf): -4.5 %
 #endif
@@ -229,7 +237,7 @@ __device__ __forceinline__ int32_t split_run_regular(int32_t code, const f3 o, c
                      : [code] "+v"(code), [save] "=&s"(save), [cur] "=&s"(cur), [cnt] "=&s"(cnt)
                      : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
                        [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
-                       [lim] "s"(sc.lds_nodes << 4), [n1off] "i"(N1OFF)
+                       [lim] "s"(N1OFF), [n1off] "i"(N1OFF)
                      : "vcc", "scc", "memory", PT_RUN_CLOBBERS);
     }
 #undef PT_RUN_TEST
@@ -304,7 +312,7 @@ __device__ __forceinline__ int32_t split_run_regular_fast(int32_t code, const f3
                      : [code] "+v"(code), [save] "=&s"(save), [cur] "=&s"(cur), [cnt] "=&s"(cnt)
                      : [nx] "v"(noi.x), [ny] "v"(noi.y), [nz] "v"(noi.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [t] "v"(closest),
                        [rs0] "s"(rs0), [rs1] "s"(rs1), [tmin] "s"(T_MIN), [nspl] "s"(n_split_end), [keep] "s"(keep),
-                       [lim] "s"(sc.lds_nodes << 4), [n1off] "i"(N1OFF)
+                       [lim] "s"(N1OFF), [n1off] "i"(N1OFF)
                      : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
     }
 #undef PT_RUN_TEST_FAST
@@ -334,7 +342,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     const int slot = lane % P, chunk = lane / P;
     const int tiles_x = (cam.width + tw - 1) / tw;
     const int S = rp.S;
-    const int n_nodes = sc.n_nodes << PT_CODE_SHIFT;   // in code units: the code that ends a walk
+    const int n_nodes = sc.end_slot << PT_CODE_SHIFT;  // the code that ends a walk; every Split code -- a node's or a chain entry's -- is below it
     const __amdgpu_buffer_rsrc_t n1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.n1, 0, sc.n_nodes * 16, 0x00020000);
 
   // A wave renders ONE item: a tile's pixels x a contiguous piece of the sample indices.
@@ -384,6 +392,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     // the walk stands on a node (Split: [0, n_nodes), Leaf: sign bit set), n_nodes when
     // the walk has just ended, and three values above it for the other states.
     const int32_t C_DONE = n_nodes + 1;
+    const int32_t C_PARK = n_nodes + 2;   // the walk has ended on a hit whose material waits for company (PT_PARK_MIN)
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
     f3 inv = fill(0.0f);
 #ifdef PT_FAST_MODE
@@ -417,13 +426,22 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
 
     // Where a PRIMARY ray's walk starts.  A camera ray through this wave's pixels can only hit the few spheres
     // whose (slightly inflated) balls meet the pixel block's frustum: primary_list_kernel lists their Leaves per 8x8
-    // pixel block (2.2 on average on the bench scenes; Scene::cand).  The wave copies its block's Leaves into a
-    // chain of its own in LDS -- same node format, each entry's `next` the following entry, the last one's the end
-    // code -- and its primary rays walk that chain instead of the tree: the same Sphere::trace per candidate, in
-    // the same order of ranks, without the 21.6 box tests a walk from the root spends on finding them.  The closest
-    // hit is the same: a sphere that is not in the list cannot be hit by a ray of the block, and a box test never
-    // changes which hit is closest as long as boxes contain what is below them (the host only builds lists for such
-    // trees).  A block with more than PT_PRIMARY_K candidates walks the tree as before.
+    // pixel block (2.2 on average on the bench scenes; Scene::cand).  The wave builds a chain of its own in LDS out of
+    // them -- per candidate a Split entry carrying the box of the Leaf's PARENT (box passed: the Leaf's entry; missed:
+    // the next candidate) and the Leaf's entry (then the next candidate; after the last one the end code) -- and its
+    // regular primary rays walk that chain instead of the tree: per candidate the LAST box test the reference's walk
+    // makes before it reaches the Leaf, then the same Sphere::trace, in the same order of ranks.
+    //   Why the parent's box, and why it is enough: far from the eye Sphere::trace is much less exact than a slab test
+    // (its discriminant b^2 - a c carries an absolute error of a few 2^-24 |oc|^2 |d|^2: for a sphere of radius 0.2
+    // at distance 200 that is half of r^2 |d|^2), so it "hits" for rays that pass above the sphere -- rays the
+    // reference never gets to test, because they miss every box on the way.  The boxes filter what the sphere test sees,
+    // and the filter has to stay.  But the boxes on the way are nested (a Split's box is the min / max of its
+    // children's: exact in fp32) and the slab test is monotone in the box for a ray without NaNs ((b - o) * inv and
+    // min / max are monotone under rounding): a ray that passes the parent's test passes every ancestor's.  So
+    // "reaches the Leaf" is decided by the parent's box alone; what differs from the reference's walk is only the
+    // closest hit a box is tested against at that moment, as with any other visiting order.
+    // Rays that are not REGULAR (a NaN or an infinity in the slab test breaks the monotony) walk the tree, and so does
+    // a block with more than PT_PRIMARY_K candidates.  The host builds lists only for trees whose boxes are nested.
     int32_t primary_code = sc.root_code;
     if (N1OFF == PT_LDS_N1_OFFSET && !EXT && sc.cand) {
         const int ctile = ((tile / tiles_x) * th >> 3) * sc.cand_tiles_x + ((tile % tiles_x) * tw >> 3);
@@ -431,16 +449,24 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         const int32_t first = __builtin_amdgcn_readfirstlane(mine);
         if (first != 1) {                                                        // 1: too many candidates, walk the tree
             const int count = lanes(mine != 0);
-            const uint32_t chain = (uint32_t)(PT_CHAIN_BASE + (threadIdx.x >> 6) * (16 * PT_PRIMARY_K));
+            // entries 2k (the Split) and 2k + 1 (the Leaf) of this wave's chain, as byte offsets = node codes
+            const uint32_t chain = (uint32_t)(PT_CHAIN_BASE + (threadIdx.x >> 6) * (16 * PT_CHAIN_ENTRIES));
             if (mine != 0) {
+                const uint32_t split_at = chain + 32u * (uint32_t)lane, leaf_at = split_at + 16u;
+                const int32_t after = lane + 1 < count ? (int32_t)(split_at + 32u) : n_nodes;   // the next candidate's Split, or the end
                 float4 n0, n1;
-                fetch(mine, n0, n1);
-                const int32_t next = lane + 1 < count ? (int32_t)((chain + 16u * (uint32_t)(lane + 1)) | 0x80000000u) : n_nodes;
-                n1.w = __int_as_float(next);
-                lds_write(chain + 16u * (uint32_t)lane, n0);
-                lds_write(chain + 16u * (uint32_t)lane + (uint32_t)N1OFF, n1);
+                fetch(mine, n0, n1);                                             // the Leaf: (c, r^2), (-, -, rank, next)
+                const int32_t parent = sc.parent_codes[__float_as_int(n1.z)];
+                n1.w = __int_as_float(after);
+                lds_write(leaf_at, n0);
+                lds_write(leaf_at + (uint32_t)N1OFF, n1);
+                fetch(parent, n0, n1);                                           // its parent: (bmin, skip), (bmax, next)
+                n0.w = __int_as_float(after);                                    // box missed: on to the next candidate
+                n1.w = __int_as_float((int32_t)(leaf_at | 0x80000000u));         // box passed: this Leaf
+                lds_write(split_at, n0);
+                lds_write(split_at + (uint32_t)N1OFF, n1);
             }
-            primary_code = count > 0 ? (int32_t)(chain | 0x80000000u) : n_nodes;     // no candidate: the ray misses everything
+            primary_code = count > 0 ? (int32_t)chain : n_nodes;                 // no candidate: the ray misses everything
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
@@ -491,7 +517,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
 #endif
             regular = regular_ray(inv, ray.o, a, sc.bounded != 0);
             h.t = T_MAX; h.prim = -1;
-            code = new_path ? primary_code : sc.root_code;
+            code = (new_path && regular) ? primary_code : sc.root_code;
         }
         new_path = false; new_walk = false;
         PT_TIME(5);
@@ -505,13 +531,18 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         const bool all_fma_ok = __ballot(!fma_ok) == 0ull;
 #endif
         bool done = false;
+        int walking = 0;                                                         // lanes with a walk to go on with, at the last vote
         for (;;) {
             const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
+            walking = cS + cL;
             const int cZ = lanes(code == n_nodes);                               // walk ended: to be shaded
             const int vS = cS * PT_W_SPLIT, vL = cL * PT_W_LEAF, vZ = cZ * PT_W_SHADE;
             PT_TIME(4);
             if (vS >= vL && vS >= vZ) {
-                if (vS == 0) { done = true; break; }                             // no lane has work left
+                if (vS == 0) {                                                   // no lane has a walk or a shade left ...
+                    if (!PT_PARK_MIN || EXT || lanes(code == C_PARK) == 0) done = true;   // ... nor a parked hit: the item is done
+                    break;                                                       // (parked hits: one more SHADE step serves them)
+                }
                 // SPLIT run: the lanes at a Split stay in the loop (exec shrinks as they leave the
                 // state); the run ends for all of them once fewer than `keep` are left
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
@@ -575,8 +606,20 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         {
             const bool walked = code == n_nodes;
             bool ended = walked && h.prim < 0, to_sky = true;
-            PT_STAT(2, lanes(walked && h.prim >= 0));
-            if (walked && h.prim >= 0) {
+            bool shade = walked && h.prim >= 0;
+            float4 sp = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ma = sp;
+            if (!EXT) {
+                if (PT_PARK_MIN) shade = shade || code == C_PARK;                // a parked lane asks again at every SHADE step
+                if (shade) { sp = sc.prims[2 * h.prim]; ma = sc.prims[2 * h.prim + 1]; }   // the hit's 32-byte record
+                if (PT_PARK_MIN) {
+                    const int tag = __float_as_int(sp.w);
+                    const bool dear = shade && ((tag & 3) == 2 || (tag >> 2) > 0);   // a Dielectric, or a picture texture
+                    const bool serve = lanes(dear) >= PT_PARK_MIN || walking == 0;
+                    if (dear && !serve) { code = C_PARK; shade = false; }
+                }
+            }
+            PT_STAT(2, lanes(shade));
+            if (shade) {
                 f3 am; Ray nr;
                 bool scattered;
                 if (EXT) {
@@ -584,7 +627,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
                     scattered = scatter_ext(sc, ray, h, rng, am, nr, emitted, light, xf_lds);
                     if (light) rad = rad + emitted * att;                        // Material::emitted, before scatter's verdict
                 } else {
-                    scattered = scatter(sc, ray, h, rng, am, nr);
+                    scattered = scatter(sc, ray, h, sp, ma, rng, am, nr);
                 }
                 if (scattered) {
                     att = att * am;                                              // raytracer.rs:57

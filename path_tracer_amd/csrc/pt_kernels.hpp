@@ -8,13 +8,16 @@
 #endif
 #define PT_LDS_N1_OFFSET 32768   // n0[] of the staged nodes from byte 0 of the group's allocation, n1[] from here
 #define PT_PRIMARY_K 8           // primary-ray candidates per 8x8 pixel block (Scene::cand); more: that block walks the tree
-// each wave's chain of candidate leaves: PT_PRIMARY_K node entries at the TOP of each half (n0 part below
-// PT_LDS_N1_OFFSET, n1 part PT_LDS_N1_OFFSET behind it, like any staged node)
-#define PT_CHAIN_BYTES (16 * PT_PRIMARY_K * PT_WAVES_PER_GROUP)
+// each wave's chain of candidates: per candidate a Split entry holding the box of the Leaf's PARENT and the Leaf's own
+// entry -- 2 * PT_PRIMARY_K node entries at the TOP of each half (n0 part below PT_LDS_N1_OFFSET, n1 part
+// PT_LDS_N1_OFFSET behind it, like any staged node)
+#define PT_CHAIN_ENTRIES (2 * PT_PRIMARY_K)
+#define PT_CHAIN_BYTES (16 * PT_CHAIN_ENTRIES * PT_WAVES_PER_GROUP)
 #define PT_CHAIN_BASE (PT_LDS_N1_OFFSET - PT_CHAIN_BYTES)
-#define PT_MAX_LDS_NODES (PT_CHAIN_BASE / 16)        // 1920 nodes staged at most
+#define PT_MAX_LDS_NODES (PT_CHAIN_BASE / 16)        // 1792 nodes staged at most
 #define PT_FIRST_GLOBAL_SLOT (PT_LDS_N1_OFFSET / 16)  // a node that is not staged has a slot from here on: every byte offset
-                                                      // below PT_LDS_N1_OFFSET is an LDS address (staged node or chain entry)
+                                                      // below PT_LDS_N1_OFFSET is an LDS address (staged node or chain entry),
+                                                      // and the code that ends a walk is never below it (Scene::end_slot)
 
 struct RenderParams {
     uint64_t seed;
