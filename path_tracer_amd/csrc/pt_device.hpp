@@ -644,9 +644,11 @@ PTD bool scatter_at(const Scene &sc, const Ray &ray, const f3 p, const f3 n, con
     out.o = p; out.d = normalized(nd);                                           // ray.rs:19-24 (discarded when absorbed)
     return alive;
 }
-// Sphere::record (sphere.rs:37-42) + scatter for a hit sphere whose 32-byte record is (sp, ma)
-PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, const float4 sp, const float4 ma, uint64_t &rng, f3 &att, Ray &out)
+// Sphere::record (sphere.rs:37-42) + scatter for a hit sphere
+PTD bool scatter(const Scene &sc, const Ray &ray, const Hit &h, uint64_t &rng, f3 &att, Ray &out)
 {
+    const float4 sp = sc.prims[2 * h.prim];
+    const float4 ma = sc.prims[2 * h.prim + 1];
     const int2 mb = make_int2(__float_as_int(sp.w) & 3, (__float_as_int(sp.w) >> 2) - 1);   // (kind, texture or -1)
     const f3 p = ray.o + ray.d * h.t;                                            // ray.rs:26-28
     const f3 n = normalized(p - mk(sp.x, sp.y, sp.z));

@@ -79,14 +79,6 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #ifndef PT_ITEMS_PER_SLOT
 #define PT_ITEMS_PER_SLOT 64  // (piece, tile) items wanted per wave slot of the chip
 #endif
-#ifndef PT_PARK_MIN
-// A Dielectric's scatter (refract + schlick + a draw: ~60 vector instructions) and a picture texture's lookup (fp64 atan2 /
-// asin: ~300) run for the whole wave whenever ONE lane of a SHADE step needs them -- and on the bench scenes one or two
-// of a step's ~32 hit lanes do, in four steps of five.  Lanes whose hit needs either are PARKED (their own state code)
-// until PT_PARK_MIN of them wait, or no lane of the wave has a walk to go on with; then one step serves them all.  Each
-// lane still runs exactly its own operations on its own stream: only WHEN differs.  0 = never park.
-#define PT_PARK_MIN 0
-#endif
 #ifndef PT_LEAF_KEEP
 #define PT_LEAF_KEEP 2    // the same for a LEAF run (a Leaf's next node is often its sibling Leaf): -4.5 %
 #endif
@@ -392,7 +384,6 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     // the walk stands on a node (Split: [0, n_nodes), Leaf: sign bit set), n_nodes when
     // the walk has just ended, and three values above it for the other states.
     const int32_t C_DONE = n_nodes + 1;
-    const int32_t C_PARK = n_nodes + 2;   // the walk has ended on a hit whose material waits for company (PT_PARK_MIN)
     Ray ray; ray.o = fill(0.0f); ray.d = fill(0.0f);
     f3 inv = fill(0.0f);
 #ifdef PT_FAST_MODE
@@ -531,18 +522,13 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         const bool all_fma_ok = __ballot(!fma_ok) == 0ull;
 #endif
         bool done = false;
-        int walking = 0;                                                         // lanes with a walk to go on with, at the last vote
         for (;;) {
             const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
-            walking = cS + cL;
             const int cZ = lanes(code == n_nodes);                               // walk ended: to be shaded
             const int vS = cS * PT_W_SPLIT, vL = cL * PT_W_LEAF, vZ = cZ * PT_W_SHADE;
             PT_TIME(4);
             if (vS >= vL && vS >= vZ) {
-                if (vS == 0) {                                                   // no lane has a walk or a shade left ...
-                    if (!PT_PARK_MIN || EXT || lanes(code == C_PARK) == 0) done = true;   // ... nor a parked hit: the item is done
-                    break;                                                       // (parked hits: one more SHADE step serves them)
-                }
+                if (vS == 0) { done = true; break; }                             // no lane has work left
                 // SPLIT run: the lanes at a Split stay in the loop (exec shrinks as they leave the
                 // state); the run ends for all of them once fewer than `keep` are left
                 const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
@@ -606,20 +592,8 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         {
             const bool walked = code == n_nodes;
             bool ended = walked && h.prim < 0, to_sky = true;
-            bool shade = walked && h.prim >= 0;
-            float4 sp = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ma = sp;
-            if (!EXT) {
-                if (PT_PARK_MIN) shade = shade || code == C_PARK;                // a parked lane asks again at every SHADE step
-                if (shade) { sp = sc.prims[2 * h.prim]; ma = sc.prims[2 * h.prim + 1]; }   // the hit's 32-byte record
-                if (PT_PARK_MIN) {
-                    const int tag = __float_as_int(sp.w);
-                    const bool dear = shade && ((tag & 3) == 2 || (tag >> 2) > 0);   // a Dielectric, or a picture texture
-                    const bool serve = lanes(dear) >= PT_PARK_MIN || walking == 0;
-                    if (dear && !serve) { code = C_PARK; shade = false; }
-                }
-            }
-            PT_STAT(2, lanes(shade));
-            if (shade) {
+            PT_STAT(2, lanes(walked && h.prim >= 0));
+            if (walked && h.prim >= 0) {
                 f3 am; Ray nr;
                 bool scattered;
                 if (EXT) {
@@ -627,7 +601,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
                     scattered = scatter_ext(sc, ray, h, rng, am, nr, emitted, light, xf_lds);
                     if (light) rad = rad + emitted * att;                        // Material::emitted, before scatter's verdict
                 } else {
-                    scattered = scatter(sc, ray, h, sp, ma, rng, am, nr);
+                    scattered = scatter(sc, ray, h, rng, am, nr);
                 }
                 if (scattered) {
                     att = att * am;                                              // raytracer.rs:57
