@@ -242,16 +242,19 @@ int pt_get_walk_order(const pt_context *ctx);   /* the order in effect for the u
  * (src/scene/mod.rs:24-34 -> src/scene/bvh.rs:106-127).  For every 8x8 pixel block of the camera's frame the library
  * lists the spheres a camera ray through the block can possibly hit (2.2 on average on the bench scenes): those whose
  * ball, inflated by a margin a hundred times the fp32 rounding of the kernel's own rays and tests, meets the block's
- * cone of directions (src/raytracer.rs:77-85, src/math/camera.rs:37-44).  A primary ray then runs Sphere::trace on
- * that handful, in rank order with the same tie rule, instead of walking the tree -- 21.6 box tests per path fewer on
- * the bench scene.  The closest hit, hence the radiance, is the same bit for bit: a sphere outside the list cannot be
- * hit, and a box test never changes which hit is closest while every box contains what is below it -- the lists are
- * only built for such trees (as PT_WALK_VIEW, below), never for pt_upload_scene_ext scenes, and a block with more
- * than 8 candidates walks the tree.  What it shares with PT_WALK_VIEW's fine point (2): a hit within an fp32 rounding
- * error of the very point where a sphere touches one of its boxes, on a ray that also grazes that box within rounding,
- * could be rejected by the reference's box test and is accepted here (about 1e-13 per segment; never observed).
- * The hit-id AOV always walks the tree.  Rebuilt (a GPU kernel, then a stream sync) by pt_set_camera / pt_upload_scene /
- * pt_set_walk_order.  enabled = 0 turns the lists off (every ray walks the tree); default on.
+ * cone of directions (src/raytracer.rs:77-85, src/math/camera.rs:37-44).  A regular primary ray then makes, per
+ * candidate, the box test of the Leaf's PARENT Split and, if it passes, Sphere::trace -- in rank order, with the same
+ * tie rule -- instead of walking the tree: about 19 box tests per path fewer on the bench scene.  The parent's box
+ * decides what the reference's walk decides with all the boxes on its way: boxes are nested and the slab test
+ * (src/math/aabb.rs:25-36) is monotone in the box for a ray without NaNs, so a ray that passes the parent's test passes
+ * every ancestor's.  (The box test cannot be dropped: far from the eye Sphere::trace's discriminant is inexact enough to
+ * "hit" for rays that pass above a sphere, which the reference's boxes never let through -- the full BASELINE cfg 5
+ * frame differed in 11 pixels without it.)  Hits and radiance are the plain walk's bit for bit; what differs is only the
+ * closest hit a box is tested against at a given moment, as with PT_WALK_VIEW's fine point (2) below.  Lists are built
+ * only for trees whose boxes are nested (as PT_WALK_VIEW), never for pt_upload_scene_ext scenes or trees of fewer than
+ * 32 nodes; a block with more than 8 candidates, and any ray with a zero or non-finite direction component, walks the
+ * tree.  The hit-id AOV always walks the tree.  Rebuilt (a GPU kernel, then a stream sync) by pt_set_camera /
+ * pt_upload_scene / pt_set_walk_order.  enabled = 0 turns the lists off (every ray walks the tree); default on.
  * pt_get_primary_lists: 1 if the uploaded scene + camera render with lists, 0 if not. */
 int pt_set_primary_lists(pt_context *ctx, int32_t enabled);
 int pt_get_primary_lists(const pt_context *ctx);

@@ -822,3 +822,39 @@ def test_primary_lists_are_off_where_boxes_do_not_contain_their_spheres(renderer
         assert same_bits(rad, osc.render(cam.pod, 3, seed=2)["radiance"])
     finally:
         renderer.set_lanes_per_pixel(0)
+
+
+@pytest.mark.gpu
+def test_primary_lists_far_small_spheres_at_grazing_angles(renderer, oracle):
+    """The regime in which the first version of the lists failed on the full cfg 5 frame (11 pixels of 8.3 M): rows of
+    small spheres 150-250 units from an eye that looks along their tops.  There Sphere::trace's discriminant is inexact
+    enough (its rounding error is about half of r^2 |d|^2) to report hits for rays that pass ABOVE a sphere -- rays the
+    reference's walk never tests, because they miss the boxes, whose tops coincide with the spheres' tops.  A camera ray's
+    chain therefore carries the box test of each candidate's parent; with it the frame equals the oracle's bit for bit,
+    lists on or off."""
+    import path_tracer_amd as pt
+    scene = pt.Scene.new()
+    scene.add(pt.Sphere.new((0.0, -1000.0, 0.0), 1000.0, pt.Lambertian.new_solid((0.5, 0.5, 0.5))))
+    rnd = np.random.default_rng(5)
+    for iz in range(150, 251, 4):
+        for ix in range(-6, 7, 2):
+            mat = pt.Lambertian.new_solid(tuple(rnd.uniform(0.1, 0.9, 3))) if (ix + iz) % 3 else pt.Dielectric.new(1.5)
+            scene.add(pt.Sphere.new((ix + 0.3 * float(rnd.uniform(-1, 1)), 0.2, iz + 0.3 * float(rnd.uniform(-1, 1))), 0.2, mat))
+    renderer.set_lanes_per_pixel(1)
+    try:
+        for eye_y, fov in ((0.45, 3.0), (0.41, 1.0), (2.0, 4.0)):
+            cam = pt.Camera.new((0.0, eye_y, 0.0), (0.0, 0.38, 200.0), (0.0, 1.0, 0.0), fov, 256, 48)
+            rt = pt.Raytracer.new(cam, scene, 6)
+            osc = oracle.OracleScene(rt.packed)
+            ref = osc.render(cam.pod, 6, seed=8, hit_ids=True)
+            assert (ref["hit_id"] > 0).any() and (ref["hit_id"] == -1).any()      # small spheres and sky are both in view
+            for on in (True, False):
+                renderer.set_primary_lists(on)
+                img, rad, ids = renderer.render(rt, seed=8, radiance=True, hit_ids=True)
+                assert renderer.primary_lists() == on
+                assert np.array_equal(ids, ref["hit_id"])
+                assert same_bits(rad, ref["radiance"]), "eye height %g, lists %s: %d radiance words differ" % (
+                    eye_y, on, np.sum(rad.view(np.uint32) != ref["radiance"].view(np.uint32)))
+    finally:
+        renderer.set_primary_lists(True)
+        renderer.set_lanes_per_pixel(0)

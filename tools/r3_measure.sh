@@ -14,4 +14,7 @@ for w in final largest cornell earth; do
   echo "profile $w done"
 done
 bash tools/profile.sh r3_fast --mode fast --no-fast --steps 2 --warmup 1 > gpurun_out/r3_profile_fast.log 2>&1 || echo "profile fast failed"
+if [ -f build/variants/stats.so ]; then
+  PT_AMD_LIB=$REPO/build/variants/stats.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-fast --steps 1 --warmup 0 > gpurun_out/r3_stats.json 2> gpurun_out/r3_stats.err || echo "stats run failed"
+fi
 echo all done
