@@ -247,9 +247,10 @@ int pt_get_walk_order(const pt_context *ctx);   /* the order in effect for the u
  * tie rule -- instead of walking the tree: about 19 box tests per path fewer on the bench scene.  The parent's box
  * decides what the reference's walk decides with all the boxes on its way: boxes are nested and the slab test
  * (src/math/aabb.rs:25-36) is monotone in the box for a ray without NaNs, so a ray that passes the parent's test passes
- * every ancestor's.  (The box test cannot be dropped: far from the eye Sphere::trace's discriminant is inexact enough to
- * "hit" for rays that pass above a sphere, which the reference's boxes never let through -- the full BASELINE cfg 5
- * frame differed in 11 pixels without it.)  Hits and radiance are the plain walk's bit for bit; what differs is only the
+ * every ancestor's.  (The box test cannot be dropped: where a sphere touches its boxes and a ray grazes it there, the slab
+ * test is exact and Sphere::trace's discriminant is not, so the sphere test "hits" for rays the reference's boxes never
+ * let through -- main.rs's eye sits at the height of the big spheres' tops, and the full BASELINE cfg 5 frame differed
+ * in 11 pixels without it.)  Hits and radiance are the plain walk's bit for bit; what differs is only the
  * closest hit a box is tested against at a given moment, as with PT_WALK_VIEW's fine point (2) below.  Lists are built
  * only for trees whose boxes are nested (as PT_WALK_VIEW), never for pt_upload_scene_ext scenes or trees of fewer than
  * 32 nodes; a block with more than 8 candidates, and any ray with a zero or non-finite direction component, walks the

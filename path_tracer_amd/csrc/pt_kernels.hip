@@ -422,15 +422,17 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     // the next candidate) and the Leaf's entry (then the next candidate; after the last one the end code) -- and its
     // regular primary rays walk that chain instead of the tree: per candidate the LAST box test the reference's walk
     // makes before it reaches the Leaf, then the same Sphere::trace, in the same order of ranks.
-    //   Why the parent's box, and why it is enough: far from the eye Sphere::trace is much less exact than a slab test
-    // (its discriminant b^2 - a c carries an absolute error of a few 2^-24 |oc|^2 |d|^2: for a sphere of radius 0.2
-    // at distance 200 that is half of r^2 |d|^2), so it "hits" for rays that pass above the sphere -- rays the
-    // reference never gets to test, because they miss every box on the way.  The boxes filter what the sphere test sees,
-    // and the filter has to stay.  But the boxes on the way are nested (a Split's box is the min / max of its
-    // children's: exact in fp32) and the slab test is monotone in the box for a ray without NaNs ((b - o) * inv and
-    // min / max are monotone under rounding): a ray that passes the parent's test passes every ancestor's.  So
-    // "reaches the Leaf" is decided by the parent's box alone; what differs from the reference's walk is only the
-    // closest hit a box is tested against at that moment, as with any other visiting order.
+    //   Why the parent's box, and why it is enough: where a sphere TOUCHES its boxes and the ray grazes it there, the
+    // slab test is exact and Sphere::trace is not (its discriminant is a difference of two large numbers), so the sphere
+    // test "hits" for rays that pass just outside -- rays the reference never gets to test, because its walk stops at
+    // the box.  main.rs's eye sits at y = 2, the height of the big spheres' tops: the full cfg 5 frame has a row of
+    // horizontal rays a few 1e-6 above those poles, and differed in 11 pixels while the chain held Leaves only.  The
+    // boxes filter what the sphere test sees, and the filter has to stay.  But the boxes on the way are nested (a
+    // Split's box is the min / max of its children's: exact in fp32) and the slab test is monotone in the box for a ray
+    // without NaNs ((b - o) * inv and min / max are monotone under rounding): a ray that passes the parent's test
+    // passes every ancestor's.  So "reaches the Leaf" is decided by the parent's box alone; what differs from the
+    // reference's walk is only the closest hit a box is tested against at that moment, as with any other visiting
+    // order.
     // Rays that are not REGULAR (a NaN or an infinity in the slab test breaks the monotony) walk the tree, and so does
     // a block with more than PT_PRIMARY_K candidates.  The host builds lists only for trees whose boxes are nested.
     int32_t primary_code = sc.root_code;
