@@ -761,8 +761,15 @@ struct PathArgs { Scene sc; Camera cam; RenderParams rp; SchedParams sched; floa
 // function reads them with scalar loads): __builtin_amdgcn_kernarg_segment_ptr() is NULL inside a callee -- the
 // kernel has to hand the pointer over.  Function arguments arrive in vector registers: made uniform again first.
 typedef __attribute__((address_space(4))) const PathArgs *PathArgsPtr;
+// not_tail_called: the function uses every vector register the launch bounds allow, sixteen of them callee-saved by
+// the ABI (v40-47, v56-63) -- saved to the wave's private segment on entry and restored on exit, 9 KB per call that
+// L2 has evicted by the time the item is done: 4.8 GB of HBM traffic per headline frame for values nobody holds (the
+// loop around the call keeps three).  LLVM drops a callee's saves when it can see every caller (internal linkage,
+// no recursion, address never taken: this function) -- unless a call site carries the `tail` marker, which the
+// optimiser puts on any call that cannot reach the caller's stack, this one included.  The attribute keeps the marker
+// off; the caller then saves what IT holds across the call (two registers).
 template <bool ALL_IN_LDS, bool EXT>
-__device__ __attribute__((noinline)) void render_item_call(const uint32_t args_lo, const uint32_t args_hi, const int item_v, const uint32_t xf_lds_v)
+__device__ __attribute__((noinline, not_tail_called)) void render_item_call(const uint32_t args_lo, const uint32_t args_hi, const int item_v, const uint32_t xf_lds_v)
 {
 #if __HIP_DEVICE_COMPILE__   // the host pass has no address spaces to copy from
     const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)args_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)args_lo);
