@@ -229,8 +229,13 @@ PTD float schlick(float cosine, float r0)                                       
 // ---- P2: portable atan2f / asinf (sphere.rs:9-10), fp64 core -----------------
 PTD double atan_unit(double q)
 {
+    // pi / 4 handed over in scalar registers: as a 64-bit vector literal the compiler hoists it out of the path loop
+    // and, with no vector register to spare, spills it -- a store per lane at the start of every item
+    int qp_hi = 0x3fe921fb, qp_lo = 0x54442d18;
+    asm("" : "+s"(qp_hi), "+s"(qp_lo));
+    const double quarter_pi = __hiloint2double(qp_hi, qp_lo);
     double base = 0.0, t = q;
-    if (q > 0.41421356237309504880) { t = (q - 1.0) / (q + 1.0); base = 0.78539816339744830962; }
+    if (q > 0.41421356237309504880) { t = (q - 1.0) / (q + 1.0); base = quarter_pi; }   // 0.78539816339744830962
     double z = t * t;
     double p = 1.0 / 45.0;
 #pragma unroll

@@ -650,19 +650,28 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
     if (lane == 0 && rp.stats)
         for (int k = 0; k < 6; k++) atomicAdd(&rp.stats[8 + k], st_c[k]);
 #endif
+    // What the epilogue needs of the item's first lines -- the pixel's address, the lane's slot and chunk -- is formed
+    // again from values the loop keeps anyway (behind an empty asm, so that the compiler cannot reuse the first
+    // computation): held across the loop they were seven spilled registers per lane, written at the start of every
+    // item and read back at its end, 1.2 GB of private-segment traffic per headline frame.
+    uint32_t pixel_e = pixel;
+    int lane_e = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+v"(pixel_e), "+v"(lane_e));
+    const bool valid_e = pixel_e < (uint32_t)(cam.width * cam.height) && px < cam.width;
     if (L == 1) {
-        if (valid) { radiance[3 * pixel] = sum.x; radiance[3 * pixel + 1] = sum.y; radiance[3 * pixel + 2] = sum.z; }
+        if (valid_e) { radiance[3 * pixel_e] = sum.x; radiance[3 * pixel_e + 1] = sum.y; radiance[3 * pixel_e + 2] = sum.z; }
     } else {
         // lanes_per_pixel > 1: the pixel's chunk sums, added in chunk order by its chunk-0 lane
+        const int slot_e = lane_e % P, chunk_e = lane_e / P;
         f3 total = fill(0.0f);
-        if (resume && chunk == 0 && valid)
-            total = mk(radiance[3 * pixel], radiance[3 * pixel + 1], radiance[3 * pixel + 2]);
+        if (resume && chunk_e == 0 && valid_e)
+            total = mk(radiance[3 * pixel_e], radiance[3 * pixel_e + 1], radiance[3 * pixel_e + 2]);
         for (int k = 0; k < L; k++) {
-            const int src = k * P + slot;
+            const int src = k * P + slot_e;
             total = total + mk(__shfl(sum.x, src), __shfl(sum.y, src), __shfl(sum.z, src));
         }
-        if (chunk == 0 && valid) {
-            radiance[3 * pixel] = total.x; radiance[3 * pixel + 1] = total.y; radiance[3 * pixel + 2] = total.z;
+        if (chunk_e == 0 && valid_e) {
+            radiance[3 * pixel_e] = total.x; radiance[3 * pixel_e + 1] = total.y; radiance[3 * pixel_e + 2] = total.z;
         }
     }
     if (sched.n_pieces > 1) {

@@ -5,15 +5,19 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 src, dst, note = sys.argv[1], sys.argv[2], sys.argv[3]
 kernel = sys.argv[4] if len(sys.argv) > 4 else "path_kernel"   # substring of the kernel's name (path_kernel_fast: the PT_FAST build)
-stats = glob.glob(src + "/trace/*/*_kernel_stats.csv")[0]
+# gpurun merges every call's files into the same local directory: the newest file of each pass is this run's
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
+stats = newest(src + "/trace/*/*_kernel_stats.csv")
 shutil.copy(stats, dst + "_kernel_stats.csv")
 agg = collections.defaultdict(list)
-for f in glob.glob(src + "/pmc_*/*/*_counter_collection.csv"):
+for d in glob.glob(src + "/pmc_*/"):
+    f = newest(d + "*/*_counter_collection.csv")
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
