@@ -367,8 +367,9 @@ int thread_nodes(pt_context *c)
 
 // The primary-ray candidate lists of the current scene + camera (pt_kernels.hip primary_list_kernel; Scene::cand),
 // rebuilt whenever the camera, the scene or the node numbering changes.  Only for trees whose boxes contain what
-// is below them (view_ok: there a box test cannot change which hit is closest, so a camera ray's walk may skip the
-// boxes altogether) and never for the extension's scenes; pt_set_primary_lists(ctx, 0) turns them off.
+// is below them (view_ok: nested boxes are what lets the box test of a Leaf's PARENT stand for the tests of all its
+// ancestors -- the kernel's chains keep that one test per candidate) and never for the
+// extension's scenes; pt_set_primary_lists(ctx, 0) turns them off.
 int build_primary_lists(pt_context *c)
 {
     c->scene.cand = nullptr;

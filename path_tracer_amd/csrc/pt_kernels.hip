@@ -95,6 +95,22 @@ __device__ __forceinline__ void tile_shape(int lanes, int &tw, int &th)
 #ifndef PT_W_SHADE
 #define PT_W_SHADE 1
 #endif
+// the same for the extension's scenes (a rect test of an instance costs more than a sphere test; walks are short)
+#ifndef PT_W_SPLIT_EXT
+#define PT_W_SPLIT_EXT 3
+#endif
+#ifndef PT_W_LEAF_EXT
+#define PT_W_LEAF_EXT 5
+#endif
+#ifndef PT_W_SHADE_EXT
+#define PT_W_SHADE_EXT 1
+#endif
+#ifndef PT_LEAF_KEEP_EXT
+#define PT_LEAF_KEEP_EXT 4
+#endif
+#ifndef PT_SPLIT_KEEP_EXT
+#define PT_SPLIT_KEEP_EXT PT_SPLIT_KEEP
+#endif
 
 
 // The launch is PERSISTENT: as many workgroups as the chip holds at once (occupancy x CUs), each of 16 waves
@@ -527,13 +543,13 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
         for (;;) {
             const int cS = lanes((uint32_t)code < (uint32_t)n_nodes), cL = lanes(code < 0);
             const int cZ = lanes(code == n_nodes);                               // walk ended: to be shaded
-            const int vS = cS * PT_W_SPLIT, vL = cL * PT_W_LEAF, vZ = cZ * PT_W_SHADE;
+            const int vS = cS * (EXT ? PT_W_SPLIT_EXT : PT_W_SPLIT), vL = cL * (EXT ? PT_W_LEAF_EXT : PT_W_LEAF), vZ = cZ * (EXT ? PT_W_SHADE_EXT : PT_W_SHADE);
             PT_TIME(4);
             if (vS >= vL && vS >= vZ) {
                 if (vS == 0) { done = true; break; }                             // no lane has work left
                 // SPLIT run: the lanes at a Split stay in the loop (exec shrinks as they leave the
                 // state); the run ends for all of them once fewer than `keep` are left
-                const int keep = (cS * PT_SPLIT_KEEP + 7) >> 3;
+                const int keep = (cS * (EXT ? PT_SPLIT_KEEP_EXT : PT_SPLIT_KEEP) + 7) >> 3;
                 if ((uint32_t)code < (uint32_t)n_nodes) {
                     if (all_regular) {
 #if defined(PT_FAST_MODE) && PT_FAST_BOX
@@ -568,7 +584,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
             } else if (vL >= vZ) {
                 // LEAF run: one Sphere::trace per iteration for the lanes standing on a Leaf
                 // (extension scenes: small trees, dear rect tests -- a run goes on while half of its starters remain: -3 %)
-                const int keepL = (cL * (EXT ? 4 : PT_LEAF_KEEP) + 7) >> 3;
+                const int keepL = (cL * (EXT ? PT_LEAF_KEEP_EXT : PT_LEAF_KEEP) + 7) >> 3;
                 if (code < 0) {
                     for (;;) {
                         PT_STAT(1, lanes(true));

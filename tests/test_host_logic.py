@@ -326,3 +326,32 @@ def test_rust_binding_matches_header():
             c_consts[n] = int(v)
     r_consts = {n: int(v) for n, v in re.findall(r"pub const (PT_[A-Z_]+): \w+ = (-?\d+);", rust)}
     assert r_consts == c_consts, set(r_consts.items()) ^ set(c_consts.items())
+
+
+def test_item_call_saves_no_callee_saved_registers(tmp_path):
+    """The persistent kernel calls render_item_call once per (piece, tile) item -- 524,288 times per headline frame.
+    The function uses all 64 vector registers, 16 of them callee-saved by the ABI; saved and restored per call they
+    were 4.8 GB of HBM traffic per frame for values nobody held.  `not_tail_called` lets the compiler drop the saves
+    (DESIGN.md section 6); this test compiles the kernels' ISA and pins that: the reference scenes' item function keeps
+    two whole-wave stores (the carriers of its saved scalars) and no other access to its private segment outside the
+    texture path, so that a compiler or source change that brings the traffic back does not pass unnoticed."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "path_tracer_amd", "csrc")
+    out = tmp_path / "pt_kernels.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+                    "-x", "hip", "--cuda-device-only", "-S", "-o", str(out), "pt_kernels.hip"], cwd=csrc, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = out.read_text().split("\n")
+    for name in ("render_item_callILb1ELb0E", "render_item_callILb0ELb0E"):
+        start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + name + r"\S*:", l))
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        body = lines[start:end]
+        stores = [l for l in body if "scratch_store" in l]
+        assert len(stores) <= 2, stores
+        # the ABI's callee-saved vector registers: v40-v47, v56-v63 (of which v62, v63 carry saved scalars here)
+        saved = [l for l in stores if re.search(r"\bv(4[0-7]|5[6-9]|6[01])\b", l)]
+        assert not saved, saved
