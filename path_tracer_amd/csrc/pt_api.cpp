@@ -679,6 +679,7 @@ static int upload_common(pt_context *c, const pt_primitive *prims, int32_t n_pri
     c->scene.textures = c->d_textures;
     c->scene.xforms = c->d_xforms;
     c->scene.ext = ext ? 1 : 0;
+    c->scene.n_xforms = ext && n_xforms > 0 ? n_xforms : 0;
     c->scene.lds_xforms = (ext && n_xforms <= 128) ? n_xforms : 0;   // 4 KiB of LDS at most; more: read through the L1
     c->scene.n_nodes = n_slots;              // slots, not nodes: bounds the arrays
     c->scene.end_slot = end_slot_for(n_nodes);

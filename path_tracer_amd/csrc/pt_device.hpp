@@ -36,6 +36,7 @@ struct Scene {
     const float4 *xforms;    // per transform: (offset.xyz, sin theta), (cos theta, -, -, -)
     int32_t ext;             // 1: rendered by the extension's kernel instantiation
     int32_t lds_xforms;      // the path kernel stages this many transforms (all of them, or 0) in LDS behind the nodes
+    int32_t n_xforms;        // transforms of the scene (object-ray cache of the extension's kernel: PT_OBJ_MAX_XFORMS at most)
     // Primary-ray candidate lists (pt_kernels.hip primary_list_kernel), or NULL: per 8x8 pixel block of the current
     // camera's frame, PT_PRIMARY_K leaf codes -- every sphere a camera ray through the block can possibly hit --
     // ended by 0; a first entry of 1 = too many: walk the tree.  cand_tiles_x = blocks per row.
@@ -541,6 +542,59 @@ PTD void rect_object_ray(const Scene &sc, int flags, f3 &o, f3 &d, const uint32_
         o = rot_to_object(x, o - x.off);
         d = rot_to_object(x, d);
     }
+}
+// The object-ray cache of the extension's path kernel (pt_kernels.hip, N1OFF == PT_OBJ_N1_OFFSET): a ray's object-space
+// form depends on (ray, transform) only, and a Cornell-box walk makes seven rect tests, two thirds of them on the faces
+// of the two instanced boxes -- each of which transformed the ray again (15 operations) and then picked three of its
+// six components by the rect's axis (8 selects).  At the start of a walk the lane stores the ray as it is (slot 0)
+// and in the space of every transform (slots 1 .., the SAME operations in the same order: same bits) in LDS, one
+// (origin, direction) pair per component and lane; a rect test reads the three pairs its axis asks for.
+//   layout: slot s, component k: PT_OBJ_BASE + (3 s + k) * PT_OBJ_PLANE + 8 * thread   (float2 = (o[k], d[k]))
+#define PT_OBJ_N1_OFFSET 4096            // n1[] of the staged nodes, the ticket and the transforms: 256 entries in all
+#define PT_OBJ_BASE 8192
+#define PT_OBJ_PLANE 8192                // 1024 threads x 8 bytes
+#define PT_OBJ_MAX_XFORMS 2
+#define PT_OBJ_LDS_BYTES (PT_OBJ_BASE + 3 * (1 + PT_OBJ_MAX_XFORMS) * PT_OBJ_PLANE)   // 80 KiB: two groups per CU
+PTD float2 lds_f2(uint32_t addr)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const v2f lds_v2f;
+    const v2f t = *(lds_v2f *)(uintptr_t)addr;
+    return make_float2(t.x, t.y);
+}
+PTD void lds_put_f2(uint32_t addr, float a, float b)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2f lds_v2f;
+    const v2f t = {a, b};
+    *(lds_v2f *)(uintptr_t)addr = t;
+}
+// `at`: PT_OBJ_BASE + 8 * thread.  Slot 0 = the ray itself, slot 1 + i = in the space of transform i.
+PTD void obj_cache_fill(const Scene &sc, const uint32_t at, const f3 o, const f3 d, const uint32_t xf_lds)
+{
+    lds_put_f2(at, o.x, d.x); lds_put_f2(at + PT_OBJ_PLANE, o.y, d.y); lds_put_f2(at + 2 * PT_OBJ_PLANE, o.z, d.z);
+    for (int i = 0; i < sc.n_xforms; i++) {                                      // wave-uniform, PT_OBJ_MAX_XFORMS at most
+        const Xform x = load_xform(sc, i, xf_lds);
+        const f3 oo = rot_to_object(x, o - x.off), od = rot_to_object(x, d);     // rect_object_ray's operations
+        const uint32_t s = at + (uint32_t)(3 * (i + 1)) * PT_OBJ_PLANE;
+        lds_put_f2(s, oo.x, od.x); lds_put_f2(s + PT_OBJ_PLANE, oo.y, od.y); lds_put_f2(s + 2 * PT_OBJ_PLANE, oo.z, od.z);
+    }
+}
+// rect_step with the ray's components read from the cache (same operations on the same values as rect_step)
+PTD void rect_step_cached(const float4 n0, const float4 n1, const uint32_t at, Hit &h)
+{
+    const int flags = __float_as_int(n1.y);
+    const int axis = (flags >> 1) & 3;
+    const uint32_t s = __umul24((uint32_t)(flags >> 4), 3u * PT_OBJ_PLANE) + at;  // bits 4..: transform index + 1 = the slot
+    const uint32_t ia = axis == 0 ? PT_OBJ_PLANE : 0u, ib = axis == 2 ? PT_OBJ_PLANE : 2u * PT_OBJ_PLANE;
+    // the three reads go out together, ahead of the division (one LDS round trip per test, not two)
+    float2 k = lds_f2(s + (uint32_t)axis * PT_OBJ_PLANE), pa = lds_f2(s + ia), pb = lds_f2(s + ib);
+    asm volatile("" : "+v"(k.x), "+v"(k.y), "+v"(pa.x), "+v"(pa.y), "+v"(pb.x), "+v"(pb.y));
+    const float t = (n1.x - k.x) / k.y;
+    if (!(t < h.t && t > T_MIN)) return;
+    const float a = pa.x + pa.y * t, b = pb.x + pb.y * t;
+    if (!(a >= n0.x && a <= n0.y && b >= n0.z && b <= n0.w)) return;
+    h.t = t; h.prim = __float_as_int(n1.z);
 }
 // Traceable::trace of a rect: t = (k - o[axis]) / d[axis], accepted iff t < max_t && t > min_t (the
 // comparison of sphere.rs:57) and the point lies in [a0, a1] x [b0, b1]; a NaN fails every test

@@ -134,6 +134,9 @@ constexpr int WAVES_PER_GROUP = PT_WAVES_PER_GROUP;   // pt_kernels.hpp
 #define PT_SMALL_N1_OFFSET (16 * PT_SMALL_TREE)
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
+#ifndef PT_OBJ_CACHE
+#define PT_OBJ_CACHE 1    // the extension's kernel keeps a walk's object-space rays in LDS (pt_device.hpp obj_cache_fill)
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 8   // waves per SIMD the register allocator must leave room for (64 VGPRs)
 #endif
@@ -500,6 +503,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
 #define PT_STAT(k, n) do { } while (0)
 #define PT_TIME(k) do { } while (0)
 #endif
+    const uint32_t obj_at = (uint32_t)PT_OBJ_BASE + 8u * threadIdx.x;           // this lane's column of the object-ray cache (EXT)
     bool new_path = true, new_walk = false;
     for (;;) {
         if (new_path) {
@@ -525,6 +529,7 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
             fma_ok = __builtin_fmaxf(__builtin_fabsf(noi.x), __builtin_fmaxf(__builtin_fabsf(noi.y), __builtin_fabsf(noi.z))) <= PT_FAST_BOX_LIMIT;
 #endif
             regular = regular_ray(inv, ray.o, a, sc.bounded != 0);
+            if (EXT && N1OFF == PT_OBJ_N1_OFFSET) obj_cache_fill(sc, obj_at, ray.o, ray.d, xf_lds);
             h.t = T_MAX; h.prim = -1;
             code = (new_path && regular) ? primary_code : sc.root_code;
         }
@@ -590,7 +595,10 @@ __device__ __forceinline__ void render_item(const Scene &sc, const Camera &cam, 
                         PT_STAT(1, lanes(true));
                         float4 n0, n1;
                         fetch(code, n0, n1);
-                        if (EXT && (__float_as_int(n1.y) & 1)) rect_step(sc, n0, n1, ray.o, ray.d, h, xf_lds);
+                        if (EXT && (__float_as_int(n1.y) & 1)) {
+                            if (N1OFF == PT_OBJ_N1_OFFSET) rect_step_cached(n0, n1, obj_at, h);
+                            else rect_step(sc, n0, n1, ray.o, ray.d, h, xf_lds);
+                        }
                         else leaf_step(n0, n1, ray.o, ray.d, a, ra, PT_FAST_DIV && all_regular, h);
                         code = __float_as_int(n1.w);
                         const bool at = code < 0;
@@ -793,7 +801,7 @@ typedef __attribute__((address_space(4))) const PathArgs *PathArgsPtr;
 // no recursion, address never taken: this function) -- unless a call site carries the `tail` marker, which the
 // optimiser puts on any call that cannot reach the caller's stack, this one included.  The attribute keeps the marker
 // off; the caller then saves what IT holds across the call (two registers).
-template <bool ALL_IN_LDS, bool EXT>
+template <bool ALL_IN_LDS, bool EXT, int N1OFF>
 __device__ __attribute__((noinline, not_tail_called)) void render_item_call(const uint32_t args_lo, const uint32_t args_hi, const int item_v, const uint32_t xf_lds_v)
 {
 #if __HIP_DEVICE_COMPILE__   // the host pass has no address spaces to copy from
@@ -805,12 +813,12 @@ __device__ __attribute__((noinline, not_tail_called)) void render_item_call(cons
     const Camera cam = a->cam;
     const RenderParams rp = a->rp;
     const SchedParams sched = a->sched;
-    render_item<ALL_IN_LDS, EXT, PT_LDS_N1_OFFSET>(sc, cam, rp, sched, a->radiance, item, xf_lds);
+    render_item<ALL_IN_LDS, EXT, N1OFF>(sc, cam, rp, sched, a->radiance, item, xf_lds);
 #else
     (void)args_lo; (void)args_hi; (void)item_v; (void)xf_lds_v;
 #endif
 }
-template <bool ALL_IN_LDS, bool EXT = false>
+template <bool ALL_IN_LDS, bool EXT = false, int N1OFF = PT_LDS_N1_OFFSET>
 __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kernel_persistent(PathArgs a)
 {
     uint32_t xf_lds; int ticket_slot;
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
     const bool stamper = blockIdx.x == 0 && threadIdx.x < 64;
     unsigned long long clk0 = 0, ref0 = 0;
     if (stamper) { clk0 = __builtin_amdgcn_s_memtime(); ref0 = __builtin_amdgcn_s_memrealtime(); }
-    if (!stage_group<EXT, PT_LDS_N1_OFFSET>(a.sc, a.sched, xf_lds, ticket_slot)) return;
+    if (!stage_group<EXT, N1OFF>(a.sc, a.sched, xf_lds, ticket_slot)) return;
     __syncthreads();
     const int n_items = a.sched.n_tiles * a.sched.n_pieces;
     const uint64_t args = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // PathArgs is the kernel's only argument: offset 0
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_GROUP, PT_MIN_WAVES) void path_kerne
         t_draw += t1 - t0;
 #endif
         if (item >= n_items) break;
-        render_item_call<ALL_IN_LDS, EXT>((uint32_t)args, (uint32_t)(args >> 32), item, xf_lds);
+        render_item_call<ALL_IN_LDS, EXT, N1OFF>((uint32_t)args, (uint32_t)(args >> 32), item, xf_lds);
 #ifdef PT_PHASES
         t_item += clock64() - t1;
 #endif
@@ -1262,6 +1270,13 @@ hipError_t launch_path(const Scene &sc, const Camera &cam, const RenderParams &r
     const void *fn = nullptr;
     if (!sc.ext) fn = in_lds ? (const void *)path_kernel_persistent<true, false> : (const void *)path_kernel_persistent<false, false>;
 #ifndef PT_FAST_MODE
+    // a small extension scene (the Cornell box: 35 nodes, 2 transforms) runs the instantiation whose LDS holds the
+    // nodes in 8 KiB and, behind them, every lane's object-space rays of the walk it is on (pt_device.hpp obj_cache_fill)
+    else if (PT_OBJ_CACHE && in_lds && sc.n_xforms <= PT_OBJ_MAX_XFORMS && sc.lds_xforms == sc.n_xforms &&
+             sc.lds_nodes + 1 + 2 * sc.n_xforms <= PT_OBJ_N1_OFFSET / 16) {
+        fn = (const void *)path_kernel_persistent<true, true, PT_OBJ_N1_OFFSET>;
+        lds_bytes = PT_OBJ_LDS_BYTES;
+    }
     else fn = in_lds ? (const void *)path_kernel_persistent<true, true> : (const void *)path_kernel_persistent<false, true>;
 #else
     else return hipErrorInvalidValue;   // the FAST build carries the reference scenes' kernel only
