@@ -52,6 +52,26 @@ def test_cornell_box_bit_exact(renderer, oracle, w, h, s, lanes):
     assert rad.max() > 0.0 and set(np.unique(ids)) >= {0, 1, 2, 3, 4, 5}      # walls and the light are seen directly
 
 
+@pytest.mark.parametrize("extra_boxes", [0, 1], ids=["two_transforms_cached", "three_transforms_general"])
+def test_object_ray_cache_and_general_instantiation(renderer, oracle, extra_boxes):
+    """The Cornell box as it is runs the kernel instantiation that keeps a walk's object-space rays in LDS (at most two
+    transforms: pt_device.hpp obj_cache_fill); with a third instanced box it runs the general one.  Both equal the
+    oracle bit for bit, in both lane modes, with a glass box and a sphere among the instances (rect and sphere
+    Leaves in one LEAF run)."""
+    import path_tracer_amd as pt
+    sc = pt.Scene.new()
+    pt.cornell_box(sc)
+    sc.add(pt.Sphere.new((190.0, 90.0, 190.0), 90.0, pt.Dielectric.new(1.5)))
+    for i in range(extra_boxes):
+        tr = pt.Transform.new((60.0 + 40.0 * i, 330.0, 120.0), 33.0)
+        for r in pt.box_rects((0.0, 0.0, 0.0), (80.0, 60.0, 80.0), pt.Metal.new((0.8, 0.8, 0.9), 0.1), tr):
+            sc.add(r)
+    cam = pt.Camera.new(width=96, height=96, **pt.CORNELL_CAMERA)
+    rt = pt.Raytracer.new(cam, sc, 4, integrator=pt.Integrator(max_bounces=50, background=(0.0, 0.0, 0.0)))
+    check(renderer, oracle, rt, 4, 1)
+    check(renderer, oracle, rt, 4, 0)
+
+
 def test_cornell_box_full_frame_size_reduced_spp(renderer, oracle):
     """BASELINE config 4's frame (1024 x 1024) at 9 spp, bounce cap 50"""
     check(renderer, oracle, cornell(1024, 1024, 3), 3)
