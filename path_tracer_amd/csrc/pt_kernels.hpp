@@ -6,7 +6,9 @@
 #ifndef PT_WAVES_PER_GROUP
 #define PT_WAVES_PER_GROUP 16
 #endif
+#ifndef PT_LDS_N1_OFFSET
 #define PT_LDS_N1_OFFSET 32768   // n0[] of the staged nodes from byte 0 of the group's allocation, n1[] from here
+#endif
 #define PT_PRIMARY_K 8           // primary-ray candidates per 8x8 pixel block (Scene::cand); more: that block walks the tree
 // each wave's chain of candidates: per candidate a Split entry holding the box of the Leaf's PARENT and the Leaf's own
 // entry -- 2 * PT_PRIMARY_K node entries at the TOP of each half (n0 part below PT_LDS_N1_OFFSET, n1 part
